@@ -1,0 +1,29 @@
+# Build recipe: the HIP library (product) and the CPU checker (test infrastructure).
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+ARCH ?= gfx950
+
+LIB := ray_tracing_amd/libmrt.so
+ORACLE := oracle/libmrt_oracle.so
+CSRC := ray_tracing_amd/csrc
+
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function
+CXXFLAGS := -O3 -std=c++17 -fPIC -Wall -Wextra
+
+all: lib oracle
+
+lib: $(LIB)
+
+$(LIB): $(CSRC)/mrt_device.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_internal.h include/mrt.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/mrt_device.hip $(CSRC)/mrt_host.cpp
+
+oracle: $(ORACLE)
+
+# -march=native is deliberately NOT used: the .so is built here and run on the GPU box's host.
+$(ORACLE): oracle/cpu_ref.cpp oracle/octree_ref.h include/mrt.h
+	$(CXX) $(CXXFLAGS) -shared -pthread -o $@ oracle/cpu_ref.cpp
+
+clean:
+	rm -f $(LIB) $(ORACLE)
+
+.PHONY: all lib oracle clean

@@ -1,0 +1,1439 @@
+// mrt_device.hip -- gfx950 wavefront path tracer behind the C ABI of include/mrt.h.
+//
+// Execution model: a pool of path slots lives in HBM as structure-of-arrays
+// (ray origin/direction/time as seven f64 streams, throughput as three f32
+// streams, pixel, RNG key, segment counter). One "segment kernel" launch
+// advances every live slot by up to `segments_per_launch` path segments
+// (nearest-hit query + material response). A slot whose path ended claims the
+// next pixel-sample from a global work counter (wave-aggregated: ballot +
+// popcount + one atomic per wave) and regenerates a camera ray in place, so
+// waves stay full until the work runs out; after that the survivors are packed
+// to the front of the pool by a ballot/prefix-sum compaction kernel.
+//
+// Every device function cites the reference lines it implements
+// (paths relative to cpu_rt/src/).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "mrt_internal.h"
+
+namespace mrt {
+
+// ============================================================== device-side views
+struct SceneView {
+    const double* bmin_x;
+    const double* bmin_y;
+    const double* bmin_z;
+    const double* bmax_x;
+    const double* bmax_y;
+    const double* bmax_z;
+    const int32_t* node_object;
+    const int32_t* node_skip;
+    const int32_t* node_flags;
+    int32_t n_nodes;
+    int32_t n_objects;
+    int32_t n_lights;
+    int32_t trace_zero_throughput;
+    const DObject* objects;
+    const DObject* lights;
+    const DShape* shapes;
+    const DMaterial* materials;
+    const DTexture* textures;
+    const DImage* images;
+    const float* image_pool;
+    const DOctree* octrees;
+    const mrt_oct_node* oct_nodes;
+    const uint32_t* oct_children;
+    const mrt_voxel* oct_voxels;
+    DCamera cam;
+    mrt_background bg;
+    mrt_sun sun;
+};
+
+struct Pool {
+    double *ox, *oy, *oz, *dx, *dy, *dz, *tm;
+    float *tr, *tg, *tb;
+    uint32_t* pixel;
+    uint64_t* key;
+    int32_t* seg;  // >= 0: index of the next segment of a live path; < 0: free slot
+};
+
+struct Counters {
+    unsigned long long work_next;
+    unsigned long long rays;
+    unsigned long long light_queries;
+    unsigned int live;
+    unsigned int compacted;
+};
+
+struct RenderParams {
+    float* accum;
+    uint32_t width, height, x0, strip_w;
+    unsigned long long n_work;      // strip_w * height * spp
+    unsigned long long npix_strip;  // strip_w * height
+    uint64_t seed, first_sample;
+    uint32_t n_slots;
+    uint32_t steps;
+};
+
+// ============================================================== small vector math
+struct D3 {
+    double x, y, z;
+};
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ D3 operator*(double s, D3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ D3 operator*(D3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ D3 operator/(D3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ D3 cross(D3 a, D3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ double magnitude(D3 a) { return sqrt(dot(a, a)); }
+// cgmath normalize: self * (1 / magnitude)
+__device__ __forceinline__ D3 normalize(D3 a) { return a * (1.0 / magnitude(a)); }
+__device__ __forceinline__ double comp(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+__device__ __forceinline__ D3 ld3(const double* p) { return {p[0], p[1], p[2]}; }
+
+struct RayD {
+    D3 o, d;
+    double time;
+};
+__device__ __forceinline__ D3 ray_at(const RayD& r, double t) { return r.o + t * r.d; }  // prelude.rs:161-165
+
+struct F3 {
+    float r, g, b;
+};
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return {a.r * b.r, a.g * b.g, a.b * b.b}; }
+
+// ============================================================== counter-based RNG (contract: include/mrt.h)
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t path_key(uint64_t seed, uint64_t pixel, uint64_t sample) {
+    return mix64(mix64(seed + 0x9E3779B97F4A7C15ULL * (pixel + 1)) ^ (0xD1B54A32D192ED03ULL * (sample + 1)));
+}
+struct Rng {
+    uint64_t key;
+    uint32_t seg;
+};
+__device__ __forceinline__ uint64_t rng_u64(const Rng& g, uint32_t dim) {
+    return mix64(g.key + 0x9E3779B97F4A7C15ULL * ((((uint64_t)g.seg << 16) | dim) + 1));
+}
+__device__ __forceinline__ double rng_f64(const Rng& g, uint32_t dim) {
+    return (double)(rng_u64(g, dim) >> 11) * 0x1.0p-53;
+}
+// prelude.rs:82-84
+__device__ __forceinline__ double rand_scalar(const Rng& g, double mn, double mx, uint32_t dim) {
+    return rng_f64(g, dim) * (mx - mn) + mn;
+}
+// prelude.rs:85-87
+__device__ __forceinline__ uint32_t rand_u32(const Rng& g, uint32_t mn, uint32_t mx, uint32_t dim) {
+    return ((uint32_t)(rng_u64(g, dim) >> 32) % (mx - mn)) + mn;
+}
+// ray_tracer.rs:48-63: rejection sampling inside the unit ball, not normalised
+__device__ D3 rand_unit_vec(const Rng& g, uint32_t base) {
+    for (uint32_t k = 0; k < MRT_MAX_REJECT; ++k) {
+        D3 rv{rng_f64(g, base + 3 * k), rng_f64(g, base + 3 * k + 1), rng_f64(g, base + 3 * k + 2)};
+        D3 v = 2.0 * (rv - D3{0.5, 0.5, 0.5});
+        if (dot(v, v) < 1.0) return v;
+    }
+    return {0.0, 0.0, 0.0};
+}
+
+// ============================================================== transforms (hittable.rs:92-107)
+__device__ __forceinline__ D3 apply(const Affine& a, D3 p) {
+    return {((a.r[0][0] * p.x + a.r[0][1] * p.y) + a.r[0][2] * p.z) + a.r[0][3],
+            ((a.r[1][0] * p.x + a.r[1][1] * p.y) + a.r[1][2] * p.z) + a.r[1][3],
+            ((a.r[2][0] * p.x + a.r[2][1] * p.y) + a.r[2][2] * p.z) + a.r[2][3]};
+}
+// Transform::mul_ray: direction = M*(o+d) - M*o; never renormalised, so t is shared.
+__device__ __forceinline__ RayD xform_ray(const Affine& a, bool identity, const RayD& r) {
+    if (identity) return {r.o, (r.o + r.d) - r.o, r.time};
+    D3 e = apply(a, r.o + r.d);
+    D3 o = apply(a, r.o);
+    return {o, e - o, r.time};
+}
+
+// ============================================================== shape intersection
+// rect.rs:63-86,185-206,309-331. AXIS = constant axis (2 XY, 1 XZ, 0 YZ).
+template <int AXIS>
+__device__ __forceinline__ bool rect_hit(double a0, double a1, double b0, double b1, double k, const RayD& r,
+                                         double t_min, double t_max, double& t_out) {
+    constexpr int IA = AXIS == 0 ? 1 : 0;
+    constexpr int IB = AXIS == 2 ? 1 : 2;
+    double t = (k - comp(r.o, AXIS)) / comp(r.d, AXIS);
+    if (t < t_min || t > t_max) return false;
+    double a = comp(r.o, IA) + t * comp(r.d, IA);
+    double b = comp(r.o, IB) + t * comp(r.d, IB);
+    if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+    t_out = t;
+    return true;
+}
+// sphere.rs:28-45 (also MovingSphere :145-162 with center(time))
+__device__ __forceinline__ bool sphere_hit(D3 c, double radius, const RayD& r, double t_min, double t_max,
+                                           double& t_out) {
+    D3 rel = r.o - c;
+    double a = dot(r.d, r.d);
+    double half_b = dot(rel, r.d);
+    double cc = dot(rel, rel) - radius * radius;
+    double disc = half_b * half_b - a * cc;
+    if (disc < 0.0) return false;
+    double sq = sqrt(disc);
+    double root = (-half_b - sq) / a;
+    if (root < t_min || t_max < root) {
+        root = (-half_b + sq) / a;
+        if (root < t_min || t_max < root) return false;
+    }
+    t_out = root;
+    return true;
+}
+// sphere.rs:139-142
+__device__ __forceinline__ D3 moving_center(const double* p, double time) {
+    double f = (time - p[7]) / (p[8] - p[7]);
+    return D3{p[1], p[2], p[3]} + f * (D3{p[4], p[5], p[6]} - D3{p[1], p[2], p[3]});
+}
+// render_box.rs:117-129: faces in order xy+, xy-, xz+, xz-, yz+, yz-; strictly smaller t replaces.
+__device__ __forceinline__ bool box_hit(const double* p, const RayD& r, double t_min, double t_max, double& t_out,
+                                        int& face) {
+    bool any = false;
+    double best = 0.0, t;
+    int f = 0;
+    if (rect_hit<2>(p[0], p[3], p[1], p[4], p[5], r, t_min, t_max, t)) { any = true, best = t, f = 0; }
+    if (rect_hit<2>(p[0], p[3], p[1], p[4], p[2], r, t_min, t_max, t) && (!any || t < best)) { any = true, best = t, f = 1; }
+    if (rect_hit<1>(p[0], p[3], p[2], p[5], p[4], r, t_min, t_max, t) && (!any || t < best)) { any = true, best = t, f = 2; }
+    if (rect_hit<1>(p[0], p[3], p[2], p[5], p[1], r, t_min, t_max, t) && (!any || t < best)) { any = true, best = t, f = 3; }
+    if (rect_hit<0>(p[1], p[4], p[2], p[5], p[3], r, t_min, t_max, t) && (!any || t < best)) { any = true, best = t, f = 4; }
+    if (rect_hit<0>(p[1], p[4], p[2], p[5], p[0], r, t_min, t_max, t) && (!any || t < best)) { any = true, best = t, f = 5; }
+    t_out = best;
+    face = f;
+    return any;
+}
+
+// Deterministic shapes (everything a ConstantMedium may wrap). `sub` = box face.
+__device__ __forceinline__ bool solid_hit(const DShape& sh, const RayD& r, double t_min, double t_max, double& t,
+                                          int& sub) {
+    const double* p = sh.p;
+    sub = 0;
+    switch (sh.kind) {
+        case MRT_SHAPE_SPHERE: return sphere_hit(D3{p[1], p[2], p[3]}, p[0], r, t_min, t_max, t);
+        case MRT_SHAPE_MOVING_SPHERE: return sphere_hit(moving_center(p, r.time), p[0], r, t_min, t_max, t);
+        case MRT_SHAPE_XY_RECT: return rect_hit<2>(p[0], p[1], p[2], p[3], p[4], r, t_min, t_max, t);
+        case MRT_SHAPE_XZ_RECT: return rect_hit<1>(p[0], p[1], p[2], p[3], p[4], r, t_min, t_max, t);
+        case MRT_SHAPE_YZ_RECT: return rect_hit<0>(p[0], p[1], p[2], p[3], p[4], r, t_min, t_max, t);
+        case MRT_SHAPE_RENDER_BOX: return box_hit(p, r, t_min, t_max, t, sub);
+        default: return false;
+    }
+}
+
+// constant_medium.rs:35-93. One uniform draw at dimension `dim`.
+__device__ __forceinline__ bool medium_hit(const SceneView& sv, const DShape& sh, const RayD& r, double t_min,
+                                           double t_max, const Rng& g, uint32_t dim, double& t_out) {
+    const DShape& bnd = sv.shapes[sh.boundary];
+    double t1, t2;
+    int s;
+    if (!solid_hit(bnd, r, -10000000000.0, 10000000000.0, t1, s)) return false;
+    if (!solid_hit(bnd, r, t1 + 0.0001, 10000000000.0, t2, s)) return false;
+    if (t1 < t_min) t1 = t_min;
+    if (t2 > t_max) t2 = t_max;
+    if (t1 >= t2) return false;
+    if (t1 < 0.0) t1 = 0.0;
+    double ray_length = sqrt(r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z);
+    double distance_inside = (t2 - t1) * ray_length;
+    double neg_inv_density = -1.0 / sh.p[0];
+    double hit_distance = neg_inv_density * log(rand_scalar(g, 0.0, 1.0, dim));
+    if (hit_distance > distance_inside) return false;
+    t_out = t1 + hit_distance / ray_length;
+    return true;
+}
+
+// Object::hit (hittable.rs:204-237) without the material: returns t and the sub-shape id.
+__device__ __forceinline__ bool object_hit(const SceneView& sv, const DObject& ob, const RayD& ray, double t_min,
+                                           double t_max, const Rng& g, uint32_t medium_dim, double& t, int& sub) {
+    RayD sr = xform_ray(ob.to_object, ob.identity != 0, ray);
+    const DShape& sh = sv.shapes[ob.shape];
+    if (sh.kind == MRT_SHAPE_CONSTANT_MEDIUM) {
+        sub = 0;
+        return medium_hit(sv, sh, sr, t_min, t_max, g, medium_dim, t);
+    }
+    return solid_hit(sh, sr, t_min, t_max, t, sub);
+}
+
+// Aabb::hit (bvh.rs:18-33): every axis is tested on its own against the ORIGINAL [t_min, t_max].
+__device__ __forceinline__ bool aabb_hit(D3 mn, D3 mx, const RayD& r, D3 inv_d, double t_min, double t_max) {
+    {
+        double t0 = (mn.x - r.o.x) * inv_d.x, t1 = (mx.x - r.o.x) * inv_d.x;
+        if (inv_d.x < 0.0) { double s = t0; t0 = t1; t1 = s; }
+        double lo = t0 > t_min ? t0 : t_min, hi = t1 < t_max ? t1 : t_max;
+        if (hi < lo) return false;
+    }
+    {
+        double t0 = (mn.y - r.o.y) * inv_d.y, t1 = (mx.y - r.o.y) * inv_d.y;
+        if (inv_d.y < 0.0) { double s = t0; t0 = t1; t1 = s; }
+        double lo = t0 > t_min ? t0 : t_min, hi = t1 < t_max ? t1 : t_max;
+        if (hi < lo) return false;
+    }
+    {
+        double t0 = (mn.z - r.o.z) * inv_d.z, t1 = (mx.z - r.o.z) * inv_d.z;
+        if (inv_d.z < 0.0) { double s = t0; t0 = t1; t1 = s; }
+        double lo = t0 > t_min ? t0 : t_min, hi = t1 < t_max ? t1 : t_max;
+        if (hi < lo) return false;
+    }
+    return true;
+}
+
+// Leaf box of a MovingSphere-based object for the time window (t0, t1) the reference passes
+// (bvh.rs:142-145,180; sphere.rs:175-186; hittable.rs:239-282).
+__device__ void dynamic_leaf_box(const SceneView& sv, const DObject& ob, double t0, double t1, D3& mn, D3& mx) {
+    const DShape* sh = &sv.shapes[ob.shape];
+    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = &sv.shapes[sh->boundary];
+    const double* p = sh->p;
+    D3 c0 = moving_center(p, t0), c1 = moving_center(p, t1);
+    D3 r{p[0], p[0], p[0]};
+    D3 lo0 = c0 - r, hi0 = c0 + r, lo1 = c1 - r, hi1 = c1 + r;
+    D3 smn{lo0.x < lo1.x ? lo0.x : lo1.x, lo0.y < lo1.y ? lo0.y : lo1.y, lo0.z < lo1.z ? lo0.z : lo1.z};
+    D3 smx{hi0.x > hi1.x ? hi0.x : hi1.x, hi0.y > hi1.y ? hi0.y : hi1.y, hi0.z > hi1.z ? hi0.z : hi1.z};
+    D3 a = apply(ob.to_world, smn), b = apply(ob.to_world, smx);
+    mn = {a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y, a.z < b.z ? a.z : b.z};
+    mx = {a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y, a.z > b.z ? a.z : b.z};
+}
+
+struct HitD {
+    double t;
+    int obj;
+    int sub;
+};
+
+// World::nearest_hit (world.rs:112-114) -> BvhTreeNode::hit (bvh.rs:135-167), stackless over the
+// pre-order node arrays. Visiting left before right with t_max = left.t and preferring the
+// right result on ties is the same as keeping one running closest t and accepting t <= closest.
+__device__ bool nearest_hit(const SceneView& sv, const RayD& ray, const Rng& g, HitD& out) {
+    const double t_min = (double)0.001f;
+    double closest = (double)FLT_MAX;
+    int best_obj = -1, best_sub = 0;
+    uint32_t medium_ordinal = 0;
+    D3 inv_d{1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z};
+    int i = 0;
+    const int n = sv.n_nodes;
+    while (i < n) {
+        const int obj = sv.node_object[i];
+        const int flags = sv.node_flags[i];
+        D3 mn{sv.bmin_x[i], sv.bmin_y[i], sv.bmin_z[i]};
+        D3 mx{sv.bmax_x[i], sv.bmax_y[i], sv.bmax_z[i]};
+        if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(sv, sv.objects[obj], t_min, closest, mn, mx);
+        if (!aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
+            i = sv.node_skip[i];
+            continue;
+        }
+        if (obj >= 0) {
+            const DObject& ob = sv.objects[obj];
+            double t;
+            int sub;
+            if (object_hit(sv, ob, ray, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub)) {
+                closest = t, best_obj = obj, best_sub = sub;
+            }
+            if (sv.shapes[ob.shape].kind == MRT_SHAPE_CONSTANT_MEDIUM) medium_ordinal++;
+            if (flags & NODE_TWICE) {
+                // second leaf of a span-1 node: box re-tested against the updated bound, new draw
+                if (aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
+                    if (object_hit(sv, ob, ray, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub)) {
+                        closest = t, best_obj = obj, best_sub = sub;
+                    }
+                    medium_ordinal++;
+                }
+            }
+        }
+        i = i + 1;
+    }
+    out.t = closest;
+    out.obj = best_obj;
+    out.sub = best_sub;
+    return best_obj >= 0;
+}
+
+// ============================================================== surface data at a hit
+struct Surface {
+    D3 pos_obj;   // hit.position as the shape computed it (object space)
+    D3 n_obj;     // geometric normal in object space (never flipped, hittable.rs:385-391)
+    D3 dir_obj;   // object-space ray direction
+    double u, v;
+    double time;  // object-space ray time (= world ray time)
+    int material;
+    bool front_face;  // as the material sees it (object space; `true` for media, constant_medium.rs:66-72)
+};
+__device__ __forceinline__ void sphere_uv(D3 p, double& u, double& v) {  // sphere.rs:111-115
+    double theta = acos(-p.y);
+    double phi = atan2(-p.z, p.x) + M_PI;
+    u = phi / (2.0 * M_PI);
+    v = theta / M_PI;
+}
+template <int AXIS>
+__device__ __forceinline__ void rect_surface(double a0, double a1, double b0, double b1, double flip, const RayD& sr,
+                                             double t, Surface& s) {
+    constexpr int IA = AXIS == 0 ? 1 : 0;
+    constexpr int IB = AXIS == 2 ? 1 : 2;
+    double a = comp(sr.o, IA) + t * comp(sr.d, IA);
+    double b = comp(sr.o, IB) + t * comp(sr.d, IB);
+    s.u = (a - a0) / (a1 - a0);
+    s.v = (b - b0) / (b1 - b0);
+    s.n_obj = {AXIS == 0 ? flip : 0.0, AXIS == 1 ? flip : 0.0, AXIS == 2 ? flip : 0.0};
+}
+__device__ void surface_at(const SceneView& sv, const DObject& ob, const RayD& ray, double t, int sub, Surface& s) {
+    RayD sr = xform_ray(ob.to_object, ob.identity != 0, ray);
+    const DShape& sh = sv.shapes[ob.shape];
+    const double* p = sh.p;
+    s.pos_obj = ray_at(sr, t);
+    s.dir_obj = sr.d;
+    s.time = sr.time;
+    s.material = sh.material;
+    s.u = 0.0, s.v = 0.0;
+    switch (sh.kind) {
+        case MRT_SHAPE_SPHERE: {
+            D3 n = (s.pos_obj - D3{p[1], p[2], p[3]}) / p[0];
+            s.n_obj = n;
+            sphere_uv(n, s.u, s.v);
+            break;
+        }
+        case MRT_SHAPE_MOVING_SPHERE: {
+            D3 n = (s.pos_obj - moving_center(p, sr.time)) / p[0];
+            s.n_obj = n;
+            sphere_uv(n, s.u, s.v);
+            break;
+        }
+        case MRT_SHAPE_XY_RECT: rect_surface<2>(p[0], p[1], p[2], p[3], p[5], sr, t, s); break;
+        case MRT_SHAPE_XZ_RECT: rect_surface<1>(p[0], p[1], p[2], p[3], p[5], sr, t, s); break;
+        case MRT_SHAPE_YZ_RECT: rect_surface<0>(p[0], p[1], p[2], p[3], p[5], sr, t, s); break;
+        case MRT_SHAPE_RENDER_BOX:  // render_box.rs:21-93: "+" faces unflipped, "-" faces flipped
+            switch (sub) {
+                case 0: rect_surface<2>(p[0], p[3], p[1], p[4], 1.0, sr, t, s); break;
+                case 1: rect_surface<2>(p[0], p[3], p[1], p[4], -1.0, sr, t, s); break;
+                case 2: rect_surface<1>(p[0], p[3], p[2], p[5], 1.0, sr, t, s); break;
+                case 3: rect_surface<1>(p[0], p[3], p[2], p[5], -1.0, sr, t, s); break;
+                case 4: rect_surface<0>(p[1], p[4], p[2], p[5], 1.0, sr, t, s); break;
+                default: rect_surface<0>(p[1], p[4], p[2], p[5], -1.0, sr, t, s); break;
+            }
+            break;
+        default:  // ConstantMedium: normal (1,0,0), uv (0,0), front_face true for the phase function
+            s.n_obj = {1.0, 0.0, 0.0};
+            break;
+    }
+    s.front_face = sh.kind == MRT_SHAPE_CONSTANT_MEDIUM ? true : (dot(sr.d, s.n_obj) <= 0.0);
+}
+__device__ __forceinline__ D3 normal_to_world(const DObject& ob, D3 n) {  // hittable.rs:215-220
+    if (ob.identity) return n;
+    // cgmath Matrix3 * Vector3 = col0*x + col1*y + col2*z; normal_m holds rows
+    return {(ob.normal_m[0][0] * n.x + ob.normal_m[0][1] * n.y) + ob.normal_m[0][2] * n.z,
+            (ob.normal_m[1][0] * n.x + ob.normal_m[1][1] * n.y) + ob.normal_m[1][2] * n.z,
+            (ob.normal_m[2][0] * n.x + ob.normal_m[2][1] * n.y) + ob.normal_m[2][2] * n.z};
+}
+__device__ __forceinline__ D3 point_to_world(const DObject& ob, D3 p) {
+    if (ob.identity) return p;
+    return apply(ob.to_world, p);
+}
+
+// ============================================================== textures (texture.rs)
+__device__ __forceinline__ uint32_t f64_as_index(double v, uint32_t hi) {  // Rust `as usize` then clamp
+    if (!(v > 0.0)) return 0;
+    if (v >= (double)hi) return hi;
+    return (uint32_t)v;
+}
+__device__ F3 texture_color(const SceneView& sv, int tex, double u, double v, D3 pos) {
+    F3 acc{1.f, 1.f, 1.f};
+    int stack[8];
+    int sp = 0;
+    int cur = tex;
+    for (int guard = 0; guard < 64; ++guard) {
+        const DTexture& t = sv.textures[cur];
+        bool leaf = true;
+        F3 c{0.f, 0.f, 0.f};
+        switch (t.kind) {
+            case MRT_TEX_SOLID: c = {t.color[0], t.color[1], t.color[2]}; break;
+            case MRT_TEX_IMAGE: {  // parallel_image.rs:66-71
+                const DImage& im = sv.images[t.image];
+                uint32_t x = f64_as_index(u * ((double)im.width - 1.0), (uint32_t)im.width - 1);
+                double vv = 1.0 - v;
+                uint32_t y = f64_as_index(vv * ((double)im.height - 1.0), (uint32_t)im.height - 1);
+                const float* px = sv.image_pool + im.offset + ((size_t)x + (size_t)y * (size_t)im.width) * 3;
+                c = {px[0], px[1], px[2]};
+                break;
+            }
+            case MRT_TEX_DEBUG_V:  // texture.rs:231-238
+                c = (v != v) ? F3{0.f, 0.f, 0.f} : F3{(float)v, (float)v, (float)v};
+                break;
+            case MRT_TEX_MULTIPLY:  // texture.rs:29-31
+                if (sp < 8) stack[sp++] = t.b;
+                cur = t.a;
+                leaf = false;
+                break;
+            default: {  // MRT_TEX_CHECKER, texture.rs:62-69
+                double s = sin(10.0 * pos.x) * sin(10.0 * pos.y) * sin(10.0 * pos.z);
+                cur = s < 0.0 ? t.a : t.b;
+                leaf = false;
+                break;
+            }
+        }
+        if (leaf) {
+            acc = acc * c;
+            if (sp == 0) break;
+            cur = stack[--sp];
+        }
+    }
+    return acc;
+}
+
+// ============================================================== light list (pdf.rs, world.rs:98-110)
+// prob() of the light shapes (rect.rs:94-106,214-227,339-351; sphere.rs:63-70; render_box.rs:137-155)
+template <int AXIS>
+__device__ __forceinline__ double rect_prob(double a0, double a1, double b0, double b1, double k, D3 origin) {
+    constexpr int IA = AXIS == 0 ? 1 : 0;
+    constexpr int IB = AXIS == 2 ? 1 : 2;
+    double c[3];
+    c[IA] = 0.5 * (a0 + a1);
+    c[IB] = 0.5 * (b0 + b1);
+    c[AXIS] = 0.5 * (k + k);
+    D3 to_light = D3{c[0], c[1], c[2]} - origin;
+    double cos_alpha = fabs(comp(normalize(to_light), AXIS));
+    if (cos_alpha < 0.00001) return 0.0;
+    double area = (a1 - a0) * (b1 - b0);
+    return dot(to_light, to_light) / (cos_alpha * area);
+}
+__device__ double shape_prob(const SceneView& sv, const DShape* sh, const RayD& r) {
+    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = &sv.shapes[sh->boundary];  // constant_medium.rs:98-100
+    const double* p = sh->p;
+    switch (sh->kind) {
+        case MRT_SHAPE_SPHERE: {
+            double area = M_PI * (p[0] * p[0]);
+            D3 to_light = D3{p[1], p[2], p[3]} - r.o;
+            return dot(to_light, to_light) / area;
+        }
+        case MRT_SHAPE_XY_RECT: return rect_prob<2>(p[0], p[1], p[2], p[3], p[4], r.o);
+        case MRT_SHAPE_XZ_RECT: return rect_prob<1>(p[0], p[1], p[2], p[3], p[4], r.o);
+        case MRT_SHAPE_YZ_RECT: return rect_prob<0>(p[0], p[1], p[2], p[3], p[4], r.o);
+        case MRT_SHAPE_RENDER_BOX: {
+            double area = 0.0;
+            area += r.d.x >= 0.0 ? rect_prob<0>(p[1], p[4], p[2], p[5], p[0], r.o) : rect_prob<0>(p[1], p[4], p[2], p[5], p[3], r.o);
+            area += r.d.y >= 0.0 ? rect_prob<1>(p[0], p[3], p[2], p[5], p[1], r.o) : rect_prob<1>(p[0], p[3], p[2], p[5], p[4], r.o);
+            area += r.d.z >= 0.0 ? rect_prob<2>(p[0], p[3], p[1], p[4], p[2], r.o) : rect_prob<2>(p[0], p[3], p[1], p[4], p[5], r.o);
+            return area;
+        }
+        default: return 0.0;
+    }
+}
+struct AreaInfo {  // hittable.rs:450-456
+    RayD to_area;
+    double area;
+    D3 direction, normal, end_point;
+};
+template <int AXIS>
+__device__ __forceinline__ void rect_generate(double a0, double a1, double b0, double b1, double k, double flip,
+                                              D3 origin, double time, const Rng& g, AreaInfo& o) {
+    constexpr int IA = AXIS == 0 ? 1 : 0;
+    constexpr int IB = AXIS == 2 ? 1 : 2;
+    double c[3];
+    c[IA] = rand_scalar(g, a0, a1, MRT_DIM_LIGHT_A);
+    c[IB] = rand_scalar(g, b0, b1, MRT_DIM_LIGHT_B);
+    c[AXIS] = k;
+    D3 end_point{c[0], c[1], c[2]};
+    o.to_area = {origin, normalize(end_point - origin), time};
+    o.normal = {AXIS == 0 ? flip : 0.0, AXIS == 1 ? flip : 0.0, AXIS == 2 ? flip : 0.0};
+    o.area = (a1 - a0) * (b1 - b0);
+    o.direction = end_point - origin;
+    o.end_point = end_point;
+}
+__device__ void shape_generate(const SceneView& sv, const DShape* sh, D3 origin, double time, const Rng& g,
+                               AreaInfo& o) {
+    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = &sv.shapes[sh->boundary];  // constant_medium.rs:101-103
+    const double* p = sh->p;
+    switch (sh->kind) {
+        case MRT_SHAPE_SPHERE: {  // sphere.rs:72-87
+            D3 sd = rand_unit_vec(g, MRT_DIM_LIGHT_SPHERE);
+            D3 end_point = D3{p[1], p[2], p[3]} + p[0] * sd;
+            o.to_area = {origin, normalize(end_point - origin), time};
+            o.normal = sd;
+            o.area = M_PI * (p[0] * p[0]);
+            o.direction = end_point - origin;
+            o.end_point = end_point;
+            break;
+        }
+        case MRT_SHAPE_XY_RECT: rect_generate<2>(p[0], p[1], p[2], p[3], p[4], p[5], origin, time, g, o); break;
+        case MRT_SHAPE_XZ_RECT: rect_generate<1>(p[0], p[1], p[2], p[3], p[4], p[5], origin, time, g, o); break;
+        case MRT_SHAPE_YZ_RECT: rect_generate<0>(p[0], p[1], p[2], p[3], p[4], p[5], origin, time, g, o); break;
+        default: {  // RenderBox, render_box.rs:157-181
+            uint32_t face = rand_u32(g, 0, 3, MRT_DIM_LIGHT_FACE);
+            D3 c{(p[0] + p[3]) / 2.0, (p[1] + p[4]) / 2.0, (p[2] + p[5]) / 2.0};
+            D3 to_self = c - origin;
+            if (face == 0) {
+                if (to_self.x >= 0.0) rect_generate<0>(p[1], p[4], p[2], p[5], p[0], -1.0, origin, time, g, o);
+                else rect_generate<0>(p[1], p[4], p[2], p[5], p[3], 1.0, origin, time, g, o);
+            } else if (face == 1) {
+                if (to_self.y >= 0.0) rect_generate<1>(p[0], p[3], p[2], p[5], p[1], -1.0, origin, time, g, o);
+                else rect_generate<1>(p[0], p[3], p[2], p[5], p[4], 1.0, origin, time, g, o);
+            } else {
+                if (to_self.z >= 0.0) rect_generate<2>(p[0], p[3], p[1], p[4], p[2], -1.0, origin, time, g, o);
+                else rect_generate<2>(p[0], p[3], p[1], p[4], p[5], 1.0, origin, time, g, o);
+            }
+            break;
+        }
+    }
+}
+// Object::generate_ray_in_area, hittable.rs:289-312
+__device__ void object_generate(const SceneView& sv, const DObject& ob, D3 origin, double time, const Rng& g,
+                                AreaInfo& out) {
+    const DShape* sh = &sv.shapes[ob.shape];
+    if (ob.identity) {
+        shape_generate(sv, sh, origin, time, g, out);
+        // the reference still routes every vector through the (identity) inverse
+        D3 o = out.to_area.o;
+        out.to_area.d = (o + out.to_area.d) - o;
+        out.direction = (o + out.direction) - o;
+        out.normal = (o + out.normal) - o;
+        return;
+    }
+    AreaInfo a;
+    shape_generate(sv, sh, apply(ob.to_object, origin), time, g, a);
+    const Affine& inv = ob.to_world;
+    out.end_point = apply(inv, a.end_point);
+    out.to_area = xform_ray(inv, false, a.to_area);
+    D3 sc = apply(inv, D3{1.0, 0.0, 0.0}) - apply(inv, D3{0.0, 0.0, 0.0});
+    out.area = a.area * fabs(magnitude(sc));
+    out.direction = apply(inv, a.to_area.o + a.direction) - out.to_area.o;
+    out.normal = apply(inv, a.to_area.o + a.normal) - out.to_area.o;
+}
+
+// LightPdf::value, pdf.rs:82-99 with World::nearest_light_hit, world.rs:98-110. Returns false for None.
+__device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng& g, uint32_t& light_queries,
+                                double& value) {
+    light_queries++;
+    bool any = false;
+    double best_t = 0.0;
+    int best = -1, best_sub = 0;
+    uint32_t ordinal = 0;
+    for (int i = 0; i < sv.n_lights; ++i) {
+        const DObject& ob = sv.lights[i];
+        double t;
+        int sub;
+        bool h = object_hit(sv, ob, ray, ray.time, DBL_MAX, g, MRT_DIM_LIGHT_QUERY_MEDIUM + ordinal, t, sub);
+        if (sv.shapes[ob.shape].kind == MRT_SHAPE_CONSTANT_MEDIUM) ordinal++;
+        if (!h) continue;
+        if (!any || !(best_t < t)) {  // reduce(|acc, x| if acc.t < x.t { acc } else { x })
+            any = true, best_t = t, best = i, best_sub = sub;
+        }
+    }
+    if (!any) return false;
+    const DObject& ob = sv.lights[best];
+    Surface s;
+    surface_at(sv, ob, ray, best_t, best_sub, s);
+    D3 hit_pos = point_to_world(ob, s.pos_obj);
+    D3 hit_n = normal_to_world(ob, s.n_obj);
+    D3 to_light = hit_pos - ray.o;
+    double light_cos = fabs(dot(normalize(to_light), hit_n));
+    if (light_cos >= 0.000001) {
+        // Object::prob applies the INVERSE transform to the ray (hittable.rs:284-287)
+        RayD pr{ray.o, normalize(to_light), best_t};
+        RayD tr = xform_ray(ob.to_world, ob.identity != 0, pr);
+        value = shape_prob(sv, &sv.shapes[ob.shape], tr);
+    } else {
+        value = 0.0;
+    }
+    return true;
+}
+
+// prelude.rs:103-130
+struct Onb {
+    D3 u, v, w;
+};
+__device__ __forceinline__ Onb onb_from_w(D3 n) {
+    D3 w = normalize(n);
+    D3 a = fabs(w.x) > 0.9 ? D3{0.0, 1.0, 0.0} : D3{1.0, 0.0, 0.0};
+    D3 v = normalize(cross(w, a));
+    D3 u = cross(w, v);
+    return {u, v, w};
+}
+__device__ __forceinline__ D3 sun_direction(const mrt_sun& s) {  // sun.rs:17-20
+    double r = cos(s.phi);
+    return {r * cos(s.theta), sin(s.phi), r * sin(s.theta)};
+}
+
+// LambertianPDF::generate, pdf.rs:234-282. Returns false for None.
+__device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double incoming_time, D3 hit_point,
+                                    const Rng& g, uint32_t& light_queries, D3& out_dir, double& out_value) {
+    Onb uvw = onb_from_w(pdf_normal);
+    uint32_t r = rand_u32(g, 0, 3, MRT_DIM_PDF_CHOICE);
+    D3 dir;
+    double own;
+    if (r == 0) {  // CosinePdf::generate, pdf.rs:45-60; random_cosine_direction, prelude.rs:145-153
+        double r1 = rand_scalar(g, 0.0, 1.0, MRT_DIM_COS_R1);
+        double r2 = rand_scalar(g, 0.0, 1.0, MRT_DIM_COS_R2);
+        double z = sqrt(1.0 - r2);
+        double phi = 2.0 * M_PI * r1;
+        double sr2 = sqrt(r2);
+        double x = cos(phi) * sr2, y = sin(phi) * sr2;
+        dir = normalize(x * uvw.u + y * uvw.v + z * uvw.w);
+        double c = dot(dir, uvw.w);
+        own = c <= 0.0 ? 0.0 : c / M_PI;
+    } else if (r == 1) {  // LightPdf::generate, pdf.rs:104-130
+        if (sv.n_lights == 0) return false;
+        uint32_t idx = rand_u32(g, 0, (uint32_t)sv.n_lights, MRT_DIM_LIGHT_INDEX);
+        AreaInfo ai;
+        object_generate(sv, sv.lights[idx], hit_point, incoming_time, g, ai);
+        D3 nd = normalize(ai.to_area.d);
+        double light_cos = fabs(dot(nd, ai.normal));
+        double dist_squared = dot(ai.direction, ai.direction);
+        if (!(light_cos >= 0.000001)) return false;
+        own = dist_squared / (light_cos * ai.area);
+        dir = nd;
+    } else {  // SkyPdf::generate, pdf.rs:154-193
+        if (!sv.sun.has_sun) {
+            dir = rand_unit_vec(g, MRT_DIM_SKY);
+            own = 4.0 * M_PI;
+        } else {
+            double rr = sqrt(rand_scalar(g, 0.0, 1.0, MRT_DIM_SUN_R));
+            double theta = rand_scalar(g, 0.0, 2.0 * M_PI, MRT_DIM_SUN_THETA);
+            rr = rr * sv.sun.radius;
+            D3 svv = sun_direction(sv.sun);
+            D3 k = normalize(cross(svv, D3{0.0, 0.0, 1.0}));
+            dir = cos(rr) * svv + cross(k, svv) * sin(theta) + k * dot(k, svv) * (1.0 - cos(theta));
+            double area = M_PI * (sv.sun.radius * sv.sun.radius);
+            own = area / (4.0 * M_PI);
+        }
+    }
+    RayD value_ray{hit_point, dir, 0.0};
+    double sum = 0.0;
+    int total = 0;
+    if (r != 1) {  // light_pdf.value
+        double lv;
+        if (light_pdf_value(sv, value_ray, g, light_queries, lv)) sum += lv, total++;
+    }
+    if (r != 0) {  // sin_pdf.value, pdf.rs:32-39 (direction NOT normalised here)
+        double c = dot(dir, uvw.w);
+        sum += c <= 0.0 ? 0.0 : c / M_PI;
+        total++;
+    }
+    if (r != 2) {  // sky_pdf.value, pdf.rs:135-148
+        double svl = 1.0;
+        if (sv.sun.has_sun) svl = dot(dir, sun_direction(sv.sun)) >= cos(sv.sun.radius) ? 1.0 : 0.0;
+        sum += svl;
+        total++;
+    }
+    if (total == 0) return false;
+    out_dir = dir;
+    out_value = (sum + own) / (double)(total + 1);
+    return true;
+}
+
+// ============================================================== backgrounds
+__device__ __forceinline__ F3 sky_color(double intensity, const RayD& ray) {  // sky.rs:13-28
+    D3 unit = normalize(ray.d);
+    double t = 0.5 * (unit.y + 1.0);
+    float a = (float)(1.0 - t), b = (float)t, k = (float)intensity;
+    F3 c{1.0f * a + 0.5f * b, 1.0f * a + 0.7f * b, 1.0f * a + 1.0f * b};
+    return {c.r * k, c.g * k, c.b * k};
+}
+__device__ F3 background_color(const SceneView& sv, const RayD& ray) {
+    const mrt_background& b = sv.bg;
+    if (b.kind == MRT_BG_CONSTANT) return {b.color[0], b.color[1], b.color[2]};  // constant_color.rs:12-14
+    if (b.kind == MRT_BG_SUN_SKY) {  // sun_sky.rs:32-60
+        double r = cos(b.sun_phi);
+        D3 sun_ray{r * cos(b.sun_theta), sin(b.sun_phi), r * sin(b.sun_theta)};
+        double sun_cos = dot(sun_ray, normalize(ray.d));
+        if (sun_cos > cos(b.sun_radius) && sun_cos > 0.0) {
+            float k = (float)b.sun_brightness;
+            return {k, k, k};
+        }
+    }
+    return sky_color(b.intensity, ray);
+}
+
+// ============================================================== camera (camera.rs:88-106, ray_tracer.rs:444-447)
+__device__ RayD camera_ray(const SceneView& sv, uint32_t x, uint32_t y, uint32_t width, uint32_t height,
+                           const Rng& g) {
+    const DCamera& c = sv.cam;
+    double s = ((double)x + rand_scalar(g, 0.0, 1.0, MRT_DIM_JITTER_U)) / ((double)width - 1.0);
+    double t = ((double)y + rand_scalar(g, 0.0, 1.0, MRT_DIM_JITTER_V)) / ((double)height - 1.0);
+    D3 p{0.0, 0.0, 0.0};
+    for (uint32_t k = 0; k < MRT_MAX_REJECT; ++k) {
+        D3 q{rand_scalar(g, -1.0, 1.0, MRT_DIM_LENS + 2 * k), rand_scalar(g, -1.0, 1.0, MRT_DIM_LENS + 2 * k + 1), 0.0};
+        if (dot(q, q) < 1.0) {
+            p = q;
+            break;
+        }
+    }
+    D3 rd = c.lens_radius * p;
+    D3 offset = ld3(c.u) * rd.x + ld3(c.v) * rd.y;
+    RayD r;
+    r.o = ld3(c.origin);
+    r.d = ld3(c.lower_left_corner) + s * ld3(c.horizontal) + t * ld3(c.vertical) - ld3(c.origin) - offset;
+    r.time = rand_scalar(g, c.start_time, c.end_time, MRT_DIM_TIME);
+    return r;
+}
+
+// lib.rs:8-10
+__device__ __forceinline__ D3 reflect(D3 v, D3 n) { return v - 2.0 * dot(v, n) * n; }
+
+// ============================================================== one path segment
+// RayTracingShader::ray_color, ray_tracer.rs:159-303, unrolled from recursion into
+// "throughput *= attenuation [/ value]"; the terminal value is emitted light, background or black.
+// Returns true when the path continues with `ray` / `thr` updated; otherwise `radiance` holds the
+// path's contribution (already multiplied by the throughput).
+__device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, F3& radiance,
+                             uint32_t& rays, uint32_t& light_queries) {
+    radiance = {0.f, 0.f, 0.f};
+    HitD h;
+    rays++;
+    if (!nearest_hit(sv, ray, g, h)) {
+        F3 bg = background_color(sv, ray);
+        radiance = thr * bg;
+        return false;
+    }
+    const DObject& ob = sv.objects[h.obj];
+    Surface s;
+    surface_at(sv, ob, ray, h.t, h.sub, s);
+    const DMaterial& m = sv.materials[s.material];
+    // HitRecord::new (hittable.rs:414-448): emit first, else scatter, else nothing.
+    switch (m.kind) {
+        case MRT_MAT_DIFFUSE_LIGHT: {  // material.rs:236-248
+            if (s.front_face) radiance = thr * texture_color(sv, m.texture, s.u, s.v, s.pos_obj);
+            return false;
+        }
+        case MRT_MAT_LAMBERTIAN: {  // material.rs:54-64 + ray_tracer.rs:230-268
+            F3 att = texture_color(sv, m.texture, s.u, s.v, s.pos_obj);
+            D3 pos_w = point_to_world(ob, s.pos_obj);
+            D3 n_w = normal_to_world(ob, s.n_obj);
+            D3 dir;
+            double value;
+            if (!lambertian_generate(sv, s.n_obj, ray.time, pos_w, g, light_queries, dir, value)) return false;
+            double cosine = dot(n_w, normalize(dir));  // Lambertian::scattering_pdf_fn, material.rs:30-41
+            if (cosine < 0.0) return false;
+            double scattering_pdf = cosine / M_PI;
+            if (scattering_pdf == 0.0) return false;
+            float fv = (float)(value / scattering_pdf);
+            thr = {thr.r * att.r / fv, thr.g * att.g / fv, thr.b * att.b / fv};
+            ray = {pos_w, dir, h.t};
+            break;
+        }
+        case MRT_MAT_METAL: {  // material.rs:105-124; the specular ray stays in OBJECT space
+            D3 reflected = reflect(normalize(s.dir_obj), s.n_obj);
+            if (!(dot(reflected, s.n_obj) > 0.0)) return false;
+            F3 att = texture_color(sv, m.texture, s.u, s.v, s.pos_obj);
+            thr = thr * att;
+            ray = {s.pos_obj, reflected + m.fuzz * rand_unit_vec(g, MRT_DIM_METAL_FUZZ), s.time};
+            break;
+        }
+        case MRT_MAT_DIELECTRIC: {  // material.rs:141-196
+            double ratio = s.front_face ? 1.0 / m.index_refraction : m.index_refraction;
+            D3 unit = normalize(s.dir_obj);
+            double cos_theta = fmin(dot(s.n_obj, -1.0 * unit), 1.0);
+            double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+            bool can_not_refract = (ratio * sin_theta) > 1.0;
+            double r0 = (1.0 - ratio) / (1.0 + ratio);
+            r0 = r0 * r0;
+            double om = 1.0 - cos_theta;
+            double refl = r0 + (1.0 - r0) * (om * om * om * om * om);
+            D3 dir;
+            if (can_not_refract || refl > rng_f64(g, MRT_DIM_DIELECTRIC)) {
+                dir = reflect(unit, s.n_obj);
+            } else {
+                double ct = fmin(dot(s.n_obj, -1.0 * unit), 1.0);
+                D3 perp = ratio * (unit + ct * s.n_obj);
+                D3 par = -1.0 * s.n_obj * sqrt(fabs(1.0 - dot(perp, perp)));
+                dir = perp + par;
+            }
+            thr = thr * F3{m.color[0], m.color[1], m.color[2]};
+            ray = {s.pos_obj, dir, s.time};
+            break;
+        }
+        default: {  // MRT_MAT_ISOTROPIC, material.rs:274-285
+            F3 att = texture_color(sv, m.texture, s.u, s.v, s.pos_obj);
+            thr = thr * att;
+            ray = {s.pos_obj, rand_unit_vec(g, MRT_DIM_ISOTROPIC), s.time};
+            break;
+        }
+    }
+    // A path whose throughput is exactly zero can only ever add 0 (the reference still walks it).
+    if (!sv.trace_zero_throughput && thr.r == 0.f && thr.g == 0.f && thr.b == 0.f) return false;
+    return true;
+}
+
+// ============================================================== kernels
+constexpr int BLOCK = 256;
+
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// One launch = up to `steps` segments for every slot of the pool.
+__global__ void __launch_bounds__(BLOCK) k_segments(SceneView sv, Pool pool, RenderParams rp, Counters* ctr) {
+    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+    const bool in_range = slot < rp.n_slots;
+    int32_t seg = -1;
+    RayD ray{{0, 0, 0}, {0, 0, 1}, 0};
+    F3 thr{0.f, 0.f, 0.f};
+    uint32_t pixel = 0;
+    uint64_t key = 0;
+    if (in_range) {
+        seg = pool.seg[slot];
+        if (seg >= 0) {
+            ray.o = {pool.ox[slot], pool.oy[slot], pool.oz[slot]};
+            ray.d = {pool.dx[slot], pool.dy[slot], pool.dz[slot]};
+            ray.time = pool.tm[slot];
+            thr = {pool.tr[slot], pool.tg[slot], pool.tb[slot]};
+            pixel = pool.pixel[slot];
+            key = pool.key[slot];
+        }
+    }
+    uint32_t rays = 0, light_queries = 0;
+    bool exhausted = false;
+    for (uint32_t step = 0; step < rp.steps; ++step) {
+        // ---- regeneration: free slots claim the next pixel-samples (one atomic per wave)
+        bool want = in_range && seg < 0 && !exhausted;
+        unsigned long long mask = __ballot(want);
+        if (mask) {
+            uint32_t n_want = (uint32_t)__popcll(mask);
+            unsigned long long base = 0;
+            int leader = __ffsll((long long)mask) - 1;
+            if ((int)lane_id() == leader) base = atomicAdd(&ctr->work_next, (unsigned long long)n_want);
+            base = __shfl(base, leader, 64);
+            if (want) {
+                unsigned long long w = base + (unsigned long long)__popcll(mask & ((1ULL << lane_id()) - 1ULL));
+                if (w < rp.n_work) {
+                    unsigned long long sample = w / rp.npix_strip;
+                    uint32_t pl = (uint32_t)(w - sample * rp.npix_strip);
+                    uint32_t y = pl / rp.strip_w;
+                    uint32_t x = rp.x0 + (pl - y * rp.strip_w);
+                    pixel = x + y * rp.width;
+                    key = path_key(rp.seed, (uint64_t)pixel, rp.first_sample + sample);
+                    Rng g{key, 0};
+                    ray = camera_ray(sv, x, y, rp.width, rp.height, g);
+                    thr = {1.f, 1.f, 1.f};
+                    seg = 0;
+                } else {
+                    exhausted = true;
+                }
+            }
+        }
+        if (seg >= 0) {
+            Rng g{key, (uint32_t)seg};
+            F3 radiance;
+            bool cont = path_segment(sv, ray, thr, g, radiance, rays, light_queries);
+            seg++;
+            if (cont && seg >= 50) cont = false;  // depth 50 -> 0 returns BLACK (ray_tracer.rs:166-172, :451)
+            if (!cont) {
+                // ParallelImagePart::add_xy, parallel_image.rs:328-331
+                float* px = rp.accum + (size_t)pixel * 3;
+                if (radiance.r != 0.f) atomicAdd(px + 0, radiance.r);
+                if (radiance.g != 0.f) atomicAdd(px + 1, radiance.g);
+                if (radiance.b != 0.f) atomicAdd(px + 2, radiance.b);
+                seg = -1;
+            }
+        }
+        if (!__any(seg >= 0 || (in_range && !exhausted))) break;
+    }
+    if (in_range) {
+        pool.seg[slot] = seg;
+        if (seg >= 0) {
+            pool.ox[slot] = ray.o.x, pool.oy[slot] = ray.o.y, pool.oz[slot] = ray.o.z;
+            pool.dx[slot] = ray.d.x, pool.dy[slot] = ray.d.y, pool.dz[slot] = ray.d.z;
+            pool.tm[slot] = ray.time;
+            pool.tr[slot] = thr.r, pool.tg[slot] = thr.g, pool.tb[slot] = thr.b;
+            pool.pixel[slot] = pixel;
+            pool.key[slot] = key;
+        }
+    }
+    uint32_t live = wave_sum(seg >= 0 ? 1u : 0u);
+    rays = wave_sum(rays);
+    light_queries = wave_sum(light_queries);
+    if (lane_id() == 0) {
+        if (live) atomicAdd(&ctr->live, live);
+        if (rays) atomicAdd(&ctr->rays, (unsigned long long)rays);
+        if (light_queries) atomicAdd(&ctr->light_queries, (unsigned long long)light_queries);
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_init_pool(Pool pool, uint32_t n) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) pool.seg[i] = -1;
+}
+
+// Stream compaction: live slots of `src` are packed to the front of `dst`
+// (wave64 ballot + popcount prefix, one atomic per wave).
+__global__ void __launch_bounds__(BLOCK) k_compact(Pool src, Pool dst, uint32_t n, Counters* ctr) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    bool alive = i < n && src.seg[i] >= 0;
+    unsigned long long mask = __ballot(alive);
+    if (!mask) return;
+    uint32_t base = 0;
+    int leader = __ffsll((long long)mask) - 1;
+    if ((int)lane_id() == leader) base = atomicAdd(&ctr->compacted, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (alive) {
+        uint32_t j = base + (uint32_t)__popcll(mask & ((1ULL << lane_id()) - 1ULL));
+        dst.ox[j] = src.ox[i], dst.oy[j] = src.oy[i], dst.oz[j] = src.oz[i];
+        dst.dx[j] = src.dx[i], dst.dy[j] = src.dy[i], dst.dz[j] = src.dz[i];
+        dst.tm[j] = src.tm[i];
+        dst.tr[j] = src.tr[i], dst.tg[j] = src.tg[i], dst.tb[j] = src.tb[i];
+        dst.pixel[j] = src.pixel[i];
+        dst.key[j] = src.key[i];
+        dst.seg[j] = src.seg[i];
+    }
+}
+
+// Probe kernels (parity tests).
+__global__ void __launch_bounds__(BLOCK) k_camera_rays(SceneView sv, uint32_t width, uint32_t height,
+                                                       const int32_t* pixels, uint32_t n, uint64_t seed,
+                                                       uint64_t sample, double* out) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x = (uint32_t)pixels[2 * i], y = (uint32_t)pixels[2 * i + 1];
+    Rng g{path_key(seed, (uint64_t)x + (uint64_t)y * width, sample), 0};
+    RayD r = camera_ray(sv, x, y, width, height, g);
+    double* o = out + 7 * (size_t)i;
+    o[0] = r.o.x, o[1] = r.o.y, o[2] = r.o.z, o[3] = r.d.x, o[4] = r.d.y, o[5] = r.d.z, o[6] = r.time;
+}
+__global__ void __launch_bounds__(BLOCK) k_trace_rays(SceneView sv, const double* rays, uint32_t n, uint64_t seed,
+                                                      int32_t* obj_id, double* t_out, double* normal,
+                                                      double* position, int32_t* front_face) {
+    uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double* r = rays + 7 * (size_t)i;
+    RayD ray{{r[0], r[1], r[2]}, {r[3], r[4], r[5]}, r[6]};
+    Rng g{path_key(seed, (uint64_t)i, 0), 0};
+    HitD h;
+    bool hit = nearest_hit(sv, ray, g, h);
+    D3 n_w{0, 0, 0}, p_w{0, 0, 0};
+    if (hit) {
+        const DObject& ob = sv.objects[h.obj];
+        Surface s;
+        surface_at(sv, ob, ray, h.t, h.sub, s);
+        n_w = normal_to_world(ob, s.n_obj);
+        p_w = point_to_world(ob, s.pos_obj);
+    }
+    if (obj_id) obj_id[i] = hit ? h.obj : -1;
+    if (t_out) t_out[i] = hit ? h.t : 0.0;
+    if (normal) normal[3 * (size_t)i] = n_w.x, normal[3 * (size_t)i + 1] = n_w.y, normal[3 * (size_t)i + 2] = n_w.z;
+    if (position) position[3 * (size_t)i] = p_w.x, position[3 * (size_t)i + 1] = p_w.y, position[3 * (size_t)i + 2] = p_w.z;
+    if (front_face) front_face[i] = hit ? (dot(ray.d, n_w) <= 0.0 ? 1 : 0) : 0;  // hittable.rs:222
+}
+
+}  // namespace mrt
+
+// ====================================================================== host side
+using namespace mrt;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int set_error(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return set_error(e_ == hipErrorOutOfMemory ? MRT_ERR_OUT_OF_MEMORY : MRT_ERR_DEVICE,       \
+                             std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+
+struct DeviceBuffers {
+    std::vector<void*> allocs;
+    ~DeviceBuffers() {
+        for (void* p : allocs) (void)hipFree(p);
+    }
+    template <class T>
+    int upload(const std::vector<T>& v, const T** out) {
+        *out = nullptr;
+        size_t bytes = v.size() * sizeof(T);
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+        allocs.push_back(p);
+        if (bytes) HIP_TRY(hipMemcpy(p, v.data(), bytes, hipMemcpyHostToDevice));
+        *out = static_cast<const T*>(p);
+        return MRT_OK;
+    }
+    int alloc(size_t bytes, void** out) {
+        *out = nullptr;
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+        allocs.push_back(p);
+        *out = p;
+        return MRT_OK;
+    }
+};
+
+}  // namespace
+
+struct mrt_scene {
+    FlatScene flat;
+    int device = -1;  // -1: host-only scene (no device image)
+    SceneView view{};
+    DeviceBuffers scene_mem;
+    // path pool (allocated lazily on the first render)
+    std::unique_ptr<DeviceBuffers> pool_mem;
+    Pool pool[2]{};
+    Counters* counters = nullptr;
+    uint32_t pool_slots = 0;
+    // options
+    int64_t opt_pool_slots = 1 << 22;
+    int64_t opt_steps = 4;
+    int64_t opt_trace_zero = 0;
+    int64_t opt_compact = 1;
+    std::mutex mu;
+};
+
+namespace {
+
+int upload_scene(mrt_scene* sc) {
+    FlatScene& f = sc->flat;
+    SceneView& v = sc->view;
+    DeviceBuffers& m = sc->scene_mem;
+    int rc;
+#define UP(vec, field)                                       \
+    if ((rc = m.upload(vec, &v.field)) != MRT_OK) return rc;
+    UP(f.bmin[0], bmin_x) UP(f.bmin[1], bmin_y) UP(f.bmin[2], bmin_z)
+    UP(f.bmax[0], bmax_x) UP(f.bmax[1], bmax_y) UP(f.bmax[2], bmax_z)
+    UP(f.node_object, node_object) UP(f.node_skip, node_skip) UP(f.node_flags, node_flags)
+    UP(f.objects, objects) UP(f.lights, lights) UP(f.shapes, shapes) UP(f.materials, materials)
+    UP(f.textures, textures) UP(f.images, images) UP(f.image_pool, image_pool)
+    UP(f.octrees, octrees) UP(f.oct_nodes, oct_nodes) UP(f.oct_children, oct_children) UP(f.oct_voxels, oct_voxels)
+#undef UP
+    v.n_nodes = (int32_t)f.node_object.size();
+    v.n_objects = (int32_t)f.objects.size();
+    v.n_lights = (int32_t)f.lights.size();
+    v.cam = f.camera;
+    v.bg = f.background;
+    v.sun = f.sun;
+    v.trace_zero_throughput = 0;
+    return MRT_OK;
+}
+
+int ensure_pool(mrt_scene* sc) {
+    uint32_t want = (uint32_t)std::max<int64_t>(BLOCK, std::min<int64_t>(sc->opt_pool_slots, 1 << 26));
+    want = (want + BLOCK - 1) / BLOCK * BLOCK;
+    if (sc->pool_mem && sc->pool_slots == want) return MRT_OK;
+    sc->pool_mem.reset(new DeviceBuffers());
+    DeviceBuffers& m = *sc->pool_mem;
+    int rc;
+    for (int b = 0; b < 2; ++b) {
+        Pool& p = sc->pool[b];
+        double** d7[7] = {&p.ox, &p.oy, &p.oz, &p.dx, &p.dy, &p.dz, &p.tm};
+        for (auto dp : d7)
+            if ((rc = m.alloc(sizeof(double) * want, reinterpret_cast<void**>(dp))) != MRT_OK) return rc;
+        float** f3[3] = {&p.tr, &p.tg, &p.tb};
+        for (auto fp : f3)
+            if ((rc = m.alloc(sizeof(float) * want, reinterpret_cast<void**>(fp))) != MRT_OK) return rc;
+        if ((rc = m.alloc(sizeof(uint32_t) * want, reinterpret_cast<void**>(&p.pixel))) != MRT_OK) return rc;
+        if ((rc = m.alloc(sizeof(uint64_t) * want, reinterpret_cast<void**>(&p.key))) != MRT_OK) return rc;
+        if ((rc = m.alloc(sizeof(int32_t) * want, reinterpret_cast<void**>(&p.seg))) != MRT_OK) return rc;
+    }
+    if ((rc = m.alloc(sizeof(Counters), reinterpret_cast<void**>(&sc->counters))) != MRT_OK) return rc;
+    sc->pool_slots = want;
+    return MRT_OK;
+}
+
+// Render loop on `stream`; accum is device memory.
+int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t height, uint32_t x0, uint32_t strip_w,
+                  uint32_t spp, uint64_t seed, uint64_t first_sample, hipStream_t stream, mrt_stats* stats) {
+    if (!sc || sc->device < 0) return set_error(MRT_ERR_INVALID_ARGUMENT, "scene has no device image");
+    if (!accum_dev) return set_error(MRT_ERR_INVALID_ARGUMENT, "accumulation buffer is NULL");
+    if (width < 2 || height < 2) return set_error(MRT_ERR_INVALID_ARGUMENT, "image must be at least 2x2");
+    if ((uint64_t)width * height > 0xFFFFFFFFull / 3) return set_error(MRT_ERR_INVALID_ARGUMENT, "image too large");
+    if (strip_w == 0 || (uint64_t)x0 + strip_w > width)
+        return set_error(MRT_ERR_INVALID_ARGUMENT, "strip exceeds the image width");
+    std::lock_guard<std::mutex> lock(sc->mu);
+    HIP_TRY(hipSetDevice(sc->device));
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (spp == 0) return MRT_OK;
+    int rc = ensure_pool(sc);
+    if (rc != MRT_OK) return rc;
+
+    RenderParams rp{};
+    rp.accum = accum_dev;
+    rp.width = width, rp.height = height, rp.x0 = x0, rp.strip_w = strip_w;
+    rp.npix_strip = (unsigned long long)strip_w * height;
+    rp.n_work = rp.npix_strip * spp;
+    rp.seed = seed, rp.first_sample = first_sample;
+    rp.steps = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(sc->opt_steps, 64));
+    uint32_t n_slots = (uint32_t)std::min<unsigned long long>(sc->pool_slots, (rp.n_work + BLOCK - 1) / BLOCK * BLOCK);
+    SceneView view = sc->view;
+    view.trace_zero_throughput = (int32_t)sc->opt_trace_zero;
+
+    hipEvent_t ev_begin, ev_end, ek0, ek1;
+    HIP_TRY(hipEventCreate(&ev_begin));
+    HIP_TRY(hipEventCreate(&ev_end));
+    HIP_TRY(hipEventCreate(&ek0));
+    HIP_TRY(hipEventCreate(&ek1));
+    struct EvGuard {
+        hipEvent_t e[4];
+        ~EvGuard() {
+            for (auto x : e) (void)hipEventDestroy(x);
+        }
+    } guard{{ev_begin, ev_end, ek0, ek1}};
+
+    HIP_TRY(hipEventRecord(ev_begin, stream));
+    HIP_TRY(hipMemsetAsync(sc->counters, 0, sizeof(Counters), stream));
+    int cur = 0;
+    hipLaunchKernelGGL(k_init_pool, dim3(n_slots / BLOCK), dim3(BLOCK), 0, stream, sc->pool[cur], n_slots);
+    HIP_TRY(hipGetLastError());
+
+    Counters host{};
+    double kernel_ms = 0.0;
+    uint64_t launches = 0;
+    uint32_t active = n_slots;
+    for (;;) {
+        HIP_TRY(hipMemsetAsync(&sc->counters->live, 0, sizeof(unsigned int) * 2, stream));
+        rp.n_slots = active;
+        HIP_TRY(hipEventRecord(ek0, stream));
+        hipLaunchKernelGGL(k_segments, dim3((active + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, view,
+                           sc->pool[cur], rp, sc->counters);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ek1, stream));
+        HIP_TRY(hipMemcpyAsync(&host, sc->counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ek0, ek1));
+        kernel_ms += ms;
+        launches++;
+        bool work_left = host.work_next < rp.n_work;
+        if (!work_left && host.live == 0) break;
+        if (!work_left && sc->opt_compact && host.live * 4ull < (unsigned long long)active * 3ull && active > BLOCK) {
+            // drain phase: pack the survivors so that later launches cover only live paths
+            hipLaunchKernelGGL(k_compact, dim3((active + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, sc->pool[cur],
+                               sc->pool[cur ^ 1], active, sc->counters);
+            HIP_TRY(hipGetLastError());
+            cur ^= 1;
+            active = (host.live + BLOCK - 1) / BLOCK * BLOCK;
+            if (active > host.live) {
+                // slots between live and the block boundary must read as free
+                HIP_TRY(hipMemsetAsync(sc->pool[cur].seg + host.live, 0xFF, sizeof(int32_t) * (active - host.live), stream));
+            }
+        }
+        if (launches > 100000000ull) return set_error(MRT_ERR_DEVICE, "render loop did not terminate");
+    }
+    HIP_TRY(hipEventRecord(ev_end, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    float total_ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&total_ms, ev_begin, ev_end));
+    if (stats) {
+        stats->paths = rp.n_work;
+        stats->rays = host.rays;
+        stats->light_queries = host.light_queries;
+        stats->launches = launches;
+        stats->kernel_ms = kernel_ms;
+        stats->total_ms = total_ms;
+        stats->segment_kernel_avg_ms = launches ? kernel_ms / (double)launches : 0.0;
+    }
+    return MRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrt_abi_version(void) { return MRT_ABI_VERSION; }
+
+int mrt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* mrt_last_error(void) { return g_last_error.c_str(); }
+
+mrt_scene* mrt_scene_create(const mrt_scene_desc* desc, int device, char* err, size_t errlen) {
+    auto report = [&](const std::string& msg) {
+        g_last_error = msg;
+        if (err && errlen) std::snprintf(err, errlen, "%s", msg.c_str());
+    };
+    std::unique_ptr<mrt_scene> sc(new (std::nothrow) mrt_scene());
+    if (!sc) {
+        report("out of host memory");
+        return nullptr;
+    }
+    std::string why;
+    int rc;
+    try {
+        rc = flatten_scene(desc, &sc->flat, &why);
+    } catch (const std::exception& e) {
+        rc = MRT_ERR_OUT_OF_MEMORY;
+        why = e.what();
+    }
+    if (rc != MRT_OK) {
+        report(why);
+        return nullptr;
+    }
+    sc->device = device;
+    if (device >= 0) {
+        int n = mrt_device_count();
+        if (n <= 0) {
+            report("no HIP device is visible; the HIP path is required (there is no CPU fallback)");
+            return nullptr;
+        }
+        if (device >= n) {
+            report("device ordinal out of range");
+            return nullptr;
+        }
+        if (hipSetDevice(device) != hipSuccess) {
+            report("hipSetDevice failed");
+            return nullptr;
+        }
+        if (upload_scene(sc.get()) != MRT_OK) {
+            report(g_last_error);
+            return nullptr;
+        }
+    }
+    return sc.release();
+}
+
+void mrt_scene_destroy(mrt_scene* scene) {
+    if (!scene) return;
+    if (scene->device >= 0) (void)hipSetDevice(scene->device);
+    delete scene;
+}
+
+int mrt_scene_bvh(const mrt_scene* scene, mrt_bvh_node* out, size_t capacity, size_t* n_nodes) {
+    if (!scene) return set_error(MRT_ERR_INVALID_ARGUMENT, "scene is NULL");
+    const auto& v = scene->flat.bvh_full;
+    if (n_nodes) *n_nodes = v.size();
+    if (out) {
+        if (capacity < v.size()) return set_error(MRT_ERR_INVALID_ARGUMENT, "capacity too small");
+        if (!v.empty()) std::memcpy(out, v.data(), v.size() * sizeof(mrt_bvh_node));
+    }
+    return MRT_OK;
+}
+
+int mrt_scene_set_option(mrt_scene* scene, const char* name, int64_t value) {
+    if (!scene || !name) return set_error(MRT_ERR_INVALID_ARGUMENT, "NULL argument");
+    std::lock_guard<std::mutex> lock(scene->mu);
+    std::string n(name);
+    if (n == "pool_slots") {
+        if (value < BLOCK) return set_error(MRT_ERR_INVALID_ARGUMENT, "pool_slots too small");
+        scene->opt_pool_slots = value;
+    } else if (n == "segments_per_launch") {
+        if (value < 1 || value > 64) return set_error(MRT_ERR_INVALID_ARGUMENT, "segments_per_launch must be 1..64");
+        scene->opt_steps = value;
+    } else if (n == "trace_zero_throughput") {
+        scene->opt_trace_zero = value ? 1 : 0;
+    } else if (n == "compaction") {
+        scene->opt_compact = value ? 1 : 0;
+    } else {
+        return set_error(MRT_ERR_INVALID_ARGUMENT, "unknown option: " + n);
+    }
+    return MRT_OK;
+}
+
+int mrt_camera_rays(mrt_scene* scene, uint32_t width, uint32_t height, const int32_t* pixels, size_t n,
+                    uint64_t seed, uint64_t sample_index, double* rays_out) {
+    if (!scene || scene->device < 0) return set_error(MRT_ERR_INVALID_ARGUMENT, "scene has no device image");
+    if (!pixels || !rays_out) return set_error(MRT_ERR_INVALID_ARGUMENT, "NULL buffer");
+    if (width < 2 || height < 2 || n > 0x7FFFFFFFu) return set_error(MRT_ERR_INVALID_ARGUMENT, "bad size");
+    for (size_t i = 0; i < n; ++i)
+        if (pixels[2 * i] < 0 || (uint32_t)pixels[2 * i] >= width || pixels[2 * i + 1] < 0 ||
+            (uint32_t)pixels[2 * i + 1] >= height)
+            return set_error(MRT_ERR_INVALID_ARGUMENT, "pixel outside the image");
+    if (n == 0) return MRT_OK;
+    std::lock_guard<std::mutex> lock(scene->mu);
+    HIP_TRY(hipSetDevice(scene->device));
+    DeviceBuffers tmp;
+    int32_t* dpix;
+    double* dout;
+    int rc;
+    if ((rc = tmp.alloc(sizeof(int32_t) * 2 * n, (void**)&dpix)) != MRT_OK) return rc;
+    if ((rc = tmp.alloc(sizeof(double) * 7 * n, (void**)&dout)) != MRT_OK) return rc;
+    HIP_TRY(hipMemcpy(dpix, pixels, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_camera_rays, dim3(((uint32_t)n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, scene->view, width,
+                       height, dpix, (uint32_t)n, seed, sample_index, dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(rays_out, dout, sizeof(double) * 7 * n, hipMemcpyDeviceToHost));
+    return MRT_OK;
+}
+
+int mrt_trace_rays(mrt_scene* scene, const double* rays, size_t n, uint64_t seed, int32_t* obj_id, double* t,
+                   double* normal, double* position, int32_t* front_face) {
+    if (!scene || scene->device < 0) return set_error(MRT_ERR_INVALID_ARGUMENT, "scene has no device image");
+    if (!rays && n) return set_error(MRT_ERR_INVALID_ARGUMENT, "rays is NULL");
+    if (n > 0x7FFFFFFFu) return set_error(MRT_ERR_INVALID_ARGUMENT, "too many rays");
+    if (n == 0) return MRT_OK;
+    std::lock_guard<std::mutex> lock(scene->mu);
+    HIP_TRY(hipSetDevice(scene->device));
+    DeviceBuffers tmp;
+    double *drays, *dt = nullptr, *dn = nullptr, *dp = nullptr;
+    int32_t *did = nullptr, *dff = nullptr;
+    int rc;
+    if ((rc = tmp.alloc(sizeof(double) * 7 * n, (void**)&drays)) != MRT_OK) return rc;
+    if (obj_id && (rc = tmp.alloc(sizeof(int32_t) * n, (void**)&did)) != MRT_OK) return rc;
+    if (t && (rc = tmp.alloc(sizeof(double) * n, (void**)&dt)) != MRT_OK) return rc;
+    if (normal && (rc = tmp.alloc(sizeof(double) * 3 * n, (void**)&dn)) != MRT_OK) return rc;
+    if (position && (rc = tmp.alloc(sizeof(double) * 3 * n, (void**)&dp)) != MRT_OK) return rc;
+    if (front_face && (rc = tmp.alloc(sizeof(int32_t) * n, (void**)&dff)) != MRT_OK) return rc;
+    HIP_TRY(hipMemcpy(drays, rays, sizeof(double) * 7 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_trace_rays, dim3(((uint32_t)n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, scene->view, drays,
+                       (uint32_t)n, seed, did, dt, dn, dp, dff);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (obj_id) HIP_TRY(hipMemcpy(obj_id, did, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    if (t) HIP_TRY(hipMemcpy(t, dt, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (normal) HIP_TRY(hipMemcpy(normal, dn, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+    if (position) HIP_TRY(hipMemcpy(position, dp, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+    if (front_face) HIP_TRY(hipMemcpy(front_face, dff, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    return MRT_OK;
+}
+
+int mrt_render_accumulate_device(mrt_scene* scene, float* accum_rgb_device, uint32_t width, uint32_t height,
+                                 uint32_t x0, uint32_t strip_w, uint32_t spp, uint64_t seed,
+                                 uint64_t first_sample_index, void* stream, mrt_stats* stats) {
+    return render_device(scene, accum_rgb_device, width, height, x0, strip_w, spp, seed, first_sample_index,
+                         static_cast<hipStream_t>(stream), stats);
+}
+
+int mrt_render_accumulate(mrt_scene* scene, float* accum_rgb, uint32_t width, uint32_t height, uint32_t x0,
+                          uint32_t strip_w, uint32_t spp, uint64_t seed, uint64_t first_sample_index,
+                          mrt_stats* stats) {
+    if (!scene || scene->device < 0) return set_error(MRT_ERR_INVALID_ARGUMENT, "scene has no device image");
+    if (!accum_rgb) return set_error(MRT_ERR_INVALID_ARGUMENT, "accumulation buffer is NULL");
+    if (width < 2 || height < 2 || (uint64_t)width * height > 0xFFFFFFFFull / 3)
+        return set_error(MRT_ERR_INVALID_ARGUMENT, "bad image size");
+    HIP_TRY(hipSetDevice(scene->device));
+    size_t bytes = sizeof(float) * 3 * (size_t)width * height;
+    DeviceBuffers tmp;
+    float* dacc;
+    int rc;
+    if ((rc = tmp.alloc(bytes, (void**)&dacc)) != MRT_OK) return rc;
+    HIP_TRY(hipMemcpy(dacc, accum_rgb, bytes, hipMemcpyHostToDevice));
+    rc = render_device(scene, dacc, width, height, x0, strip_w, spp, seed, first_sample_index, nullptr, stats);
+    if (rc != MRT_OK) return rc;
+    HIP_TRY(hipMemcpy(accum_rgb, dacc, bytes, hipMemcpyDeviceToHost));
+    return MRT_OK;
+}
+
+int mrt_to_image(const float* accum_rgb, uint32_t width, uint32_t height, uint32_t num_samples, uint8_t* rgb8_out) {
+    if (!accum_rgb || !rgb8_out || num_samples == 0) return set_error(MRT_ERR_INVALID_ARGUMENT, "bad argument");
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < width; ++x) {
+            const float* p = accum_rgb + ((size_t)x + (size_t)y * width) * 3;
+            uint8_t* o = rgb8_out + ((size_t)x + (size_t)(height - y - 1) * width) * 3;
+            for (int c = 0; c < 3; ++c) {
+                float s = std::sqrt(p[c] / (float)num_samples);  // rgb_color.rs:75-80
+                if (s < 0.0f) s = 0.0f;
+                else if (s > 1.0f) s = 1.0f;
+                float r = std::round(s * 255.0f);
+                o[c] = std::isnan(r) ? (uint8_t)0 : (uint8_t)r;
+            }
+        }
+    return MRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,512 @@
+// mrt_host.cpp -- host side of the scene: validates the descriptor, precomputes
+// per-object matrices, builds the BVH with the reference's construction
+// (cpu_rt/src/ray_tracer/bvh.rs:206-293) and flattens it into pre-order SoA
+// arrays with skip links for stackless traversal on the device.
+#include "mrt_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <memory>
+
+namespace mrt {
+namespace {
+
+struct Mat4 {
+    double m[4][4];  // m[col][row], cgmath layout
+};
+
+double det3x3(const double a[3][3]) {  // a[col][row]
+    return a[0][0] * (a[1][1] * a[2][2] - a[2][1] * a[1][2]) - a[1][0] * (a[0][1] * a[2][2] - a[2][1] * a[0][2]) +
+           a[2][0] * (a[0][1] * a[1][2] - a[1][1] * a[0][2]);
+}
+double minor(const Mat4& m, int col, int row) {
+    double a[3][3];
+    int ci = 0;
+    for (int c = 0; c < 4; ++c) {
+        if (c == col) continue;
+        int ri = 0;
+        for (int r = 0; r < 4; ++r) {
+            if (r == row) continue;
+            a[ci][ri++] = m.m[c][r];
+        }
+        ++ci;
+    }
+    return det3x3(a);
+}
+bool invert(const Mat4& m, Mat4* out) {
+    double det = 0.0;
+    for (int c = 0; c < 4; ++c) det += ((c & 1) ? -1.0 : 1.0) * m.m[c][0] * minor(m, c, 0);
+    if (det == 0.0 || !std::isfinite(det)) return false;
+    double inv_det = 1.0 / det;
+    for (int col = 0; col < 4; ++col)
+        for (int row = 0; row < 4; ++row) {
+            double sign = ((col + row) & 1) ? -1.0 : 1.0;
+            out->m[col][row] = minor(m, row, col) * sign * inv_det;
+        }
+    return true;
+}
+// inverse of the upper-left 3x3 (hittable.rs:206-216): columns cross products / det, transposed
+bool invert3(const Mat4& m, double out_rows[3][3]) {
+    double c[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[i][j] = m.m[i][j];
+    double det = det3x3(c);
+    if (det == 0.0 || !std::isfinite(det)) return false;
+    auto cross = [](const double* a, const double* b, double* o) {
+        o[0] = a[1] * b[2] - a[2] * b[1];
+        o[1] = a[2] * b[0] - a[0] * b[2];
+        o[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    double r[3][3];  // r[k] = k-th column of the un-transposed result = k-th ROW of the inverse
+    cross(c[1], c[2], r[0]);
+    cross(c[2], c[0], r[1]);
+    cross(c[0], c[1], r[2]);
+    for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < 3; ++j) out_rows[k][j] = r[k][j] / det;
+    return true;
+}
+Affine to_affine(const Mat4& m) {
+    Affine a;
+    for (int row = 0; row < 3; ++row)
+        for (int col = 0; col < 4; ++col) a.r[row][col] = m.m[col][row];
+    return a;
+}
+void apply(const Affine& a, const double p[3], double o[3]) {
+    for (int r = 0; r < 3; ++r) o[r] = ((a.r[r][0] * p[0] + a.r[r][1] * p[1]) + a.r[r][2] * p[2]) + a.r[r][3];
+}
+
+struct Box {
+    double mn[3], mx[3];
+};
+
+// Shape bounding boxes (sphere.rs:57-62,175-186; rect.rs:88-93,208-213,333-338; render_box.rs:131-136;
+// constant_medium.rs:95-97; fast_oct_tree/hittable.rs:69-79).
+bool shape_box(const FlatScene& s, int shape, double t0, double t1, Box* b) {
+    const DShape& sh = s.shapes[(size_t)shape];
+    const double* p = sh.p;
+    switch (sh.kind) {
+        case MRT_SHAPE_SPHERE:
+            for (int i = 0; i < 3; ++i) b->mn[i] = p[1 + i] - p[0], b->mx[i] = p[1 + i] + p[0];
+            return true;
+        case MRT_SHAPE_MOVING_SPHERE: {
+            double f0 = (t0 - p[7]) / (p[8] - p[7]), f1 = (t1 - p[7]) / (p[8] - p[7]);
+            for (int i = 0; i < 3; ++i) {
+                double c0 = p[1 + i] + f0 * (p[4 + i] - p[1 + i]);
+                double c1 = p[1 + i] + f1 * (p[4 + i] - p[1 + i]);
+                double lo0 = c0 - p[0], hi0 = c0 + p[0], lo1 = c1 - p[0], hi1 = c1 + p[0];
+                b->mn[i] = lo0 < lo1 ? lo0 : lo1;
+                b->mx[i] = hi0 > hi1 ? hi0 : hi1;
+            }
+            return true;
+        }
+        case MRT_SHAPE_XY_RECT:
+            b->mn[0] = p[0], b->mx[0] = p[1], b->mn[1] = p[2], b->mx[1] = p[3];
+            b->mn[2] = p[4] - 0.001, b->mx[2] = p[4] + 0.001;
+            return true;
+        case MRT_SHAPE_XZ_RECT:
+            b->mn[0] = p[0], b->mx[0] = p[1], b->mn[2] = p[2], b->mx[2] = p[3];
+            b->mn[1] = p[4] - 0.001, b->mx[1] = p[4] + 0.001;
+            return true;
+        case MRT_SHAPE_YZ_RECT:
+            b->mn[1] = p[0], b->mx[1] = p[1], b->mn[2] = p[2], b->mx[2] = p[3];
+            b->mn[0] = p[4] - 0.001, b->mx[0] = p[4] + 0.001;
+            return true;
+        case MRT_SHAPE_RENDER_BOX:
+            for (int i = 0; i < 3; ++i) b->mn[i] = p[i], b->mx[i] = p[3 + i];
+            return true;
+        case MRT_SHAPE_CONSTANT_MEDIUM: return shape_box(s, sh.boundary, t0, t1, b);
+        case MRT_SHAPE_OCTREE: {
+            const DOctree& o = s.octrees[(size_t)sh.octree];
+            if (o.n_nodes == 0) return false;
+            double ws = (double)(1u << o.world_log2);
+            for (int i = 0; i < 3; ++i) b->mn[i] = 0.0, b->mx[i] = ws;
+            return true;
+        }
+    }
+    return false;
+}
+// Object::bounding_box (hittable.rs:239-282): only the two corners are transformed.
+bool object_box(const FlatScene& s, const DObject& o, double t0, double t1, Box* b) {
+    Box sb;
+    if (!shape_box(s, o.shape, t0, t1, &sb)) return false;
+    double a[3], c[3];
+    apply(o.to_world, sb.mn, a);
+    apply(o.to_world, sb.mx, c);
+    for (int i = 0; i < 3; ++i) {
+        b->mn[i] = a[i] < c[i] ? a[i] : c[i];
+        b->mx[i] = a[i] > c[i] ? a[i] : c[i];
+    }
+    return true;
+}
+
+uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+struct TreeNode {
+    bool leaf = false;
+    size_t object = 0;
+    Box box{};
+    std::unique_ptr<TreeNode> left, right;
+};
+
+struct Builder {
+    const FlatScene& s;
+    std::vector<Box> box0;  // Object::bounding_box(0, 0) per object, the sort key (bvh.rs:183-196)
+    double time0, time1;
+    uint64_t rng_state;
+
+    uint32_t next_axis() {  // rand_u32(0, 2), bvh.rs:215
+        rng_state += 0x9E3779B97F4A7C15ULL;
+        return (uint32_t)(mix64(rng_state) >> 32) % 2u;
+    }
+    std::unique_ptr<TreeNode> leaf(size_t idx) {
+        auto n = std::make_unique<TreeNode>();
+        n->leaf = true;
+        n->object = idx;
+        object_box(s, s.objects[idx], time0, time1, &n->box);
+        return n;
+    }
+    // `order` = the slice of (sorted clones of) objects handed down; leaves take start + offset.
+    std::unique_ptr<TreeNode> build(const std::vector<size_t>& order, size_t offset) {
+        uint32_t axis = next_axis();
+        auto less = [&](size_t a, size_t b) { return box0[a].mn[axis] < box0[b].mn[axis]; };
+        size_t span = order.size();
+        std::unique_ptr<TreeNode> l, r;
+        if (span == 1) {
+            l = leaf(offset);
+            r = leaf(offset);
+        } else if (span == 2) {
+            if (less(order[0], order[1])) {
+                l = leaf(offset);
+                r = leaf(offset + 1);
+            } else {
+                l = leaf(offset + 1);
+                r = leaf(offset);
+            }
+        } else {
+            std::vector<size_t> sorted(order);
+            std::stable_sort(sorted.begin(), sorted.end(), less);
+            size_t middle = sorted.size() / 2;
+            std::vector<size_t> lo(sorted.begin(), sorted.begin() + (long)middle);
+            std::vector<size_t> hi(sorted.begin() + (long)middle, sorted.end());
+            l = build(lo, offset);
+            r = build(hi, offset + middle);
+        }
+        auto n = std::make_unique<TreeNode>();
+        for (int i = 0; i < 3; ++i) {  // surrounding_box, bvh.rs:34-47
+            n->box.mn[i] = l->box.mn[i] < r->box.mn[i] ? l->box.mn[i] : r->box.mn[i];
+            n->box.mx[i] = l->box.mx[i] > r->box.mx[i] ? l->box.mx[i] : r->box.mx[i];
+        }
+        n->left = std::move(l);
+        n->right = std::move(r);
+        return n;
+    }
+};
+
+bool shape_is_stochastic(const FlatScene& s, int shape) {
+    return s.shapes[(size_t)shape].kind == MRT_SHAPE_CONSTANT_MEDIUM;
+}
+bool shape_is_dynamic(const FlatScene& s, int shape) {
+    const DShape& sh = s.shapes[(size_t)shape];
+    if (sh.kind == MRT_SHAPE_MOVING_SPHERE) return true;
+    if (sh.kind == MRT_SHAPE_CONSTANT_MEDIUM) return shape_is_dynamic(s, sh.boundary);
+    return false;
+}
+
+void emit_full(const TreeNode* n, std::vector<mrt_bvh_node>* out) {
+    size_t me = out->size();
+    out->push_back(mrt_bvh_node{});
+    mrt_bvh_node rec{};
+    for (int i = 0; i < 3; ++i) rec.bmin[i] = n->box.mn[i], rec.bmax[i] = n->box.mx[i];
+    rec.object = n->leaf ? (int32_t)n->object : -1;
+    if (!n->leaf) {
+        emit_full(n->left.get(), out);
+        emit_full(n->right.get(), out);
+    }
+    rec.skip = (int32_t)out->size();
+    (*out)[me] = rec;
+}
+
+void emit_device(const FlatScene& s, const TreeNode* n, FlatScene* out) {
+    size_t me = out->node_object.size();
+    auto push = [&](const TreeNode* t, int32_t obj, int32_t flags) {
+        for (int i = 0; i < 3; ++i) out->bmin[i].push_back(t->box.mn[i]), out->bmax[i].push_back(t->box.mx[i]);
+        out->node_object.push_back(obj);
+        out->node_skip.push_back(0);
+        out->node_flags.push_back(flags);
+    };
+    if (n->leaf) {
+        int32_t flags = shape_is_dynamic(s, s.objects[n->object].shape) ? NODE_DYNAMIC_BOX : 0;
+        push(n, (int32_t)n->object, flags);
+    } else if (n->left->leaf && n->right->leaf && n->left->object == n->right->object) {
+        // Span-1 node: Child{Leaf k, Leaf k}. The parent's box equals the leaf's box, so the
+        // pair collapses into one leaf node. A deterministic shape returns the same record on
+        // the second visit (t_max = first t is accepted by the non-strict tests and rejected
+        // by the strict octree test, both leaving the first record in place); a stochastic
+        // medium draws again, so it is marked to be evaluated twice.
+        int shape = s.objects[n->left->object].shape;
+        int32_t flags = shape_is_dynamic(s, shape) ? NODE_DYNAMIC_BOX : 0;
+        if (flags & NODE_DYNAMIC_BOX) {
+            // keep the parent/leaf/leaf structure: a dynamic leaf box differs per visit
+            push(n, -1, 0);
+            emit_device(s, n->left.get(), out);
+            emit_device(s, n->right.get(), out);
+        } else {
+            if (shape_is_stochastic(s, shape)) flags |= NODE_TWICE;
+            push(n->left.get(), (int32_t)n->left->object, flags);
+        }
+    } else {
+        push(n, -1, 0);
+        emit_device(s, n->left.get(), out);
+        emit_device(s, n->right.get(), out);
+    }
+    out->node_skip[me] = (int32_t)out->node_object.size();
+}
+
+int fail(std::string* err, int code, const std::string& msg) {
+    if (err) *err = msg;
+    return code;
+}
+
+}  // namespace
+
+int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
+    if (!d || !out) return fail(err, MRT_ERR_INVALID_ARGUMENT, "null scene descriptor");
+    if (d->abi_version != MRT_ABI_VERSION) return fail(err, MRT_ERR_INVALID_ARGUMENT, "ABI version mismatch");
+    auto need = [&](uint32_t n, const void* p) { return n == 0 || p != nullptr; };
+    if (!need(d->n_textures, d->textures) || !need(d->n_images, d->images) || !need(d->n_materials, d->materials) ||
+        !need(d->n_shapes, d->shapes) || !need(d->n_objects, d->objects) || !need(d->n_lights, d->lights) ||
+        !need(d->n_octrees, d->octrees))
+        return fail(err, MRT_ERR_INVALID_ARGUMENT, "array pointer is NULL with a non-zero count");
+    FlatScene& s = *out;
+    s = FlatScene{};
+
+    for (uint32_t i = 0; i < d->n_images; ++i) {
+        const mrt_image& im = d->images[i];
+        if (im.width <= 0 || im.height <= 0 || !im.rgb) return fail(err, MRT_ERR_INVALID_ARGUMENT, "bad image");
+        DImage di{im.width, im.height, (uint64_t)s.image_pool.size()};
+        s.image_pool.insert(s.image_pool.end(), im.rgb, im.rgb + (size_t)im.width * (size_t)im.height * 3);
+        s.images.push_back(di);
+    }
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        const mrt_texture& t = d->textures[i];
+        DTexture dt{t.kind, t.a, t.b, t.image, {t.color[0], t.color[1], t.color[2]}, 0};
+        switch (t.kind) {
+            case MRT_TEX_SOLID:
+            case MRT_TEX_DEBUG_V: break;
+            case MRT_TEX_IMAGE:
+                if (t.image < 0 || (uint32_t)t.image >= d->n_images)
+                    return fail(err, MRT_ERR_INVALID_ARGUMENT, "texture: bad image index");
+                break;
+            case MRT_TEX_MULTIPLY:
+            case MRT_TEX_CHECKER:
+                if (t.a < 0 || (uint32_t)t.a >= i || t.b < 0 || (uint32_t)t.b >= i)
+                    return fail(err, MRT_ERR_INVALID_ARGUMENT, "texture: child index must precede the texture");
+                break;
+            default: return fail(err, MRT_ERR_INVALID_ARGUMENT, "unknown texture kind");
+        }
+        s.textures.push_back(dt);
+    }
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const mrt_material& m = d->materials[i];
+        if (m.kind < MRT_MAT_LAMBERTIAN || m.kind > MRT_MAT_ISOTROPIC)
+            return fail(err, MRT_ERR_INVALID_ARGUMENT, "unknown material kind");
+        if (m.kind != MRT_MAT_DIELECTRIC && (m.texture < 0 || (uint32_t)m.texture >= d->n_textures))
+            return fail(err, MRT_ERR_INVALID_ARGUMENT, "material: bad texture index");
+        s.materials.push_back(DMaterial{m.kind, m.texture, m.fuzz, m.index_refraction,
+                                        {m.color[0], m.color[1], m.color[2]}, 0});
+    }
+    for (uint32_t i = 0; i < d->n_octrees; ++i) {
+        const mrt_octree& o = d->octrees[i];
+        if (!need(o.n_nodes, o.nodes) || !need(o.n_children, o.children) || !need(o.n_voxels, o.voxels) ||
+            (o.n_children % 8) != 0)
+            return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: bad arrays");
+        DOctree dt{};
+        dt.root = o.root;
+        dt.node_offset = (uint32_t)s.oct_nodes.size();
+        dt.child_offset = (uint32_t)s.oct_children.size();
+        dt.voxel_offset = (uint32_t)s.oct_voxels.size();
+        dt.n_nodes = o.n_nodes;
+        if (o.n_nodes) {
+            if (o.root >= o.n_nodes) return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: bad root");
+            dt.world_log2 = o.nodes[o.root].size;
+            if (dt.world_log2 > 20) return fail(err, MRT_ERR_UNSUPPORTED, "octree: world larger than 2^20");
+        }
+        for (uint32_t k = 0; k < o.n_nodes; ++k) {
+            const mrt_oct_node& n = o.nodes[k];
+            if (n.kind == MRT_OCT_PARENT) {
+                if (n.first_child < 0 || (uint32_t)n.first_child + 8 > o.n_children || n.size == 0)
+                    return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: bad parent node");
+                for (int c = 0; c < 8; ++c) {
+                    uint32_t ci = o.children[(uint32_t)n.first_child + (uint32_t)c];
+                    if (ci >= o.n_nodes || o.nodes[ci].size + 1 != n.size)
+                        return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: bad child link");
+                }
+            } else if (n.kind == MRT_OCT_LEAF) {
+                if (n.voxel < 0 || (uint32_t)n.voxel >= o.n_voxels)
+                    return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: bad voxel index");
+                if (o.voxels[n.voxel].kind != MRT_VOX_LAMBERTIAN)
+                    return fail(err, MRT_ERR_UNSUPPORTED, "octree: only solid Lambertian voxels are supported");
+            } else if (n.kind != MRT_OCT_EMPTY) {
+                return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: unknown node kind");
+            }
+        }
+        s.oct_nodes.insert(s.oct_nodes.end(), o.nodes, o.nodes + o.n_nodes);
+        s.oct_children.insert(s.oct_children.end(), o.children, o.children + o.n_children);
+        s.oct_voxels.insert(s.oct_voxels.end(), o.voxels, o.voxels + o.n_voxels);
+        s.octrees.push_back(dt);
+    }
+    for (uint32_t i = 0; i < d->n_shapes; ++i) {
+        const mrt_shape& sh = d->shapes[i];
+        DShape ds{sh.kind, sh.material, sh.boundary, sh.octree, {}};
+        std::memcpy(ds.p, sh.p, sizeof(ds.p));
+        switch (sh.kind) {
+            case MRT_SHAPE_SPHERE:
+            case MRT_SHAPE_MOVING_SPHERE:
+            case MRT_SHAPE_XY_RECT:
+            case MRT_SHAPE_XZ_RECT:
+            case MRT_SHAPE_YZ_RECT:
+            case MRT_SHAPE_RENDER_BOX:
+                if (sh.material < 0 || (uint32_t)sh.material >= d->n_materials)
+                    return fail(err, MRT_ERR_INVALID_ARGUMENT, "shape: bad material index");
+                break;
+            case MRT_SHAPE_CONSTANT_MEDIUM: {
+                if (sh.material < 0 || (uint32_t)sh.material >= d->n_materials)
+                    return fail(err, MRT_ERR_INVALID_ARGUMENT, "medium: bad phase material index");
+                if (sh.boundary < 0 || (uint32_t)sh.boundary >= i)
+                    return fail(err, MRT_ERR_INVALID_ARGUMENT, "medium: boundary must be an earlier shape");
+                int bk = d->shapes[sh.boundary].kind;
+                if (bk != MRT_SHAPE_SPHERE && bk != MRT_SHAPE_RENDER_BOX && bk != MRT_SHAPE_XY_RECT &&
+                    bk != MRT_SHAPE_XZ_RECT && bk != MRT_SHAPE_YZ_RECT && bk != MRT_SHAPE_MOVING_SPHERE)
+                    return fail(err, MRT_ERR_UNSUPPORTED, "medium: unsupported boundary shape");
+                if (!(sh.p[0] != 0.0)) return fail(err, MRT_ERR_INVALID_ARGUMENT, "medium: zero density");
+                s.has_medium = true;
+                break;
+            }
+            case MRT_SHAPE_OCTREE:
+                if (sh.octree < 0 || (uint32_t)sh.octree >= d->n_octrees)
+                    return fail(err, MRT_ERR_INVALID_ARGUMENT, "shape: bad octree index");
+                break;
+            default: return fail(err, MRT_ERR_INVALID_ARGUMENT, "unknown shape kind");
+        }
+        s.shapes.push_back(ds);
+    }
+    auto mk_object = [&](const mrt_object& o, DObject* out_o, std::string* why) {
+        if (o.shape < 0 || (uint32_t)o.shape >= d->n_shapes) {
+            *why = "object: bad shape index";
+            return MRT_ERR_INVALID_ARGUMENT;
+        }
+        Mat4 m, inv;
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r) m.m[c][r] = o.world_transform[c * 4 + r];
+        if (!(m.m[0][3] == 0.0 && m.m[1][3] == 0.0 && m.m[2][3] == 0.0 && m.m[3][3] == 1.0)) {
+            *why = "object: only affine transforms (last row 0 0 0 1) are supported";
+            return MRT_ERR_UNSUPPORTED;
+        }
+        if (!invert(m, &inv)) {  // hittable.rs:69-76 expect("transform is not invertible")
+            *why = "object: transform is not invertible";
+            return MRT_ERR_INVALID_ARGUMENT;
+        }
+        out_o->shape = o.shape;
+        bool ident = true;
+        for (int c = 0; c < 4; ++c)
+            for (int r = 0; r < 4; ++r) ident = ident && (m.m[c][r] == (c == r ? 1.0 : 0.0));
+        out_o->identity = ident ? 1 : 0;
+        out_o->to_object = to_affine(m);
+        out_o->to_world = to_affine(inv);
+        if (!invert3(m, out_o->normal_m)) {
+            *why = "object: transform is not invertible";
+            return MRT_ERR_INVALID_ARGUMENT;
+        }
+        return MRT_OK;
+    };
+    s.objects.resize(d->n_objects);
+    for (uint32_t i = 0; i < d->n_objects; ++i) {
+        std::string why;
+        int rc = mk_object(d->objects[i], &s.objects[i], &why);
+        if (rc != MRT_OK) return fail(err, rc, why);
+    }
+    s.lights.resize(d->n_lights);
+    for (uint32_t i = 0; i < d->n_lights; ++i) {
+        std::string why;
+        int rc = mk_object(d->lights[i], &s.lights[i], &why);
+        if (rc != MRT_OK) return fail(err, rc, why);
+        // sphere.rs:187-192 and fast_oct_tree/hittable.rs:80-85 are todo!() in the reference
+        int k = s.shapes[(size_t)s.lights[i].shape].kind;
+        if (k == MRT_SHAPE_CONSTANT_MEDIUM) k = s.shapes[(size_t)s.shapes[(size_t)s.lights[i].shape].boundary].kind;
+        if (k == MRT_SHAPE_MOVING_SPHERE || k == MRT_SHAPE_OCTREE)
+            return fail(err, MRT_ERR_UNSUPPORTED, "light: MovingSphere / octree lights panic in the reference");
+    }
+
+    // Camera::new (camera.rs:44-76)
+    {
+        const mrt_camera_info& ci = d->camera;
+        double theta = ci.fov * M_PI / 180.0;
+        double h = std::tan(theta / 2.0);
+        double world_height = 2.0 * h;
+        double world_width = ci.aspect_ratio * world_height;
+        auto norm = [](double* v) {
+            double s = 1.0 / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+            v[0] *= s, v[1] *= s, v[2] *= s;
+        };
+        auto cross = [](const double* a, const double* b, double* o) {
+            o[0] = a[1] * b[2] - a[2] * b[1];
+            o[1] = a[2] * b[0] - a[0] * b[2];
+            o[2] = a[0] * b[1] - a[1] * b[0];
+        };
+        double w[3], u[3], v[3];
+        for (int i = 0; i < 3; ++i) w[i] = ci.origin[i] - ci.look_at[i];
+        norm(w);
+        cross(ci.up_vector, w, u);
+        norm(u);
+        cross(w, u, v);
+        DCamera& c = s.camera;
+        for (int i = 0; i < 3; ++i) {
+            c.origin[i] = ci.origin[i];
+            c.u[i] = u[i];
+            c.v[i] = v[i];
+            c.horizontal[i] = ci.focus_distance * world_width * u[i];
+            c.vertical[i] = ci.focus_distance * world_height * v[i];
+            c.lower_left_corner[i] = ci.origin[i] - c.horizontal[i] / 2.0 - c.vertical[i] / 2.0 - ci.focus_distance * w[i];
+        }
+        c.lens_radius = ci.aperture / 2.0;
+        c.start_time = ci.start_time;
+        c.end_time = ci.end_time;
+        for (int i = 0; i < 3; ++i)
+            if (!std::isfinite(c.lower_left_corner[i]) || !std::isfinite(c.horizontal[i]) || !std::isfinite(c.vertical[i]))
+                return fail(err, MRT_ERR_INVALID_ARGUMENT, "camera: degenerate frame");
+    }
+    if (d->background.kind < MRT_BG_SKY || d->background.kind > MRT_BG_CONSTANT)
+        return fail(err, MRT_ERR_INVALID_ARGUMENT, "unknown background kind");
+    s.background = d->background;
+    s.sun = d->sun;
+    if (s.sun.has_sun) {
+        // pdf.rs:176-179: panics when the sun direction is (anti)parallel to +z
+        double r = std::cos(s.sun.phi);
+        double sx = r * std::cos(s.sun.theta), sy = std::sin(s.sun.phi);
+        if (std::sqrt(sx * sx + sy * sy) < 0.01)
+            return fail(err, MRT_ERR_UNSUPPORTED, "sun direction parallel to +z panics in the reference");
+    }
+
+    // BvhTree::new (bvh.rs:78-96)
+    if (!s.objects.empty()) {
+        Builder b{s, {}, d->camera.start_time, d->camera.end_time, d->bvh_seed};
+        b.box0.resize(s.objects.size());
+        for (size_t i = 0; i < s.objects.size(); ++i)
+            if (!object_box(s, s.objects[i], 0.0, 0.0, &b.box0[i]))
+                return fail(err, MRT_ERR_INVALID_ARGUMENT, "object has no bounding box (empty octree)");
+        std::vector<size_t> order(s.objects.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        auto root = b.build(order, 0);
+        emit_full(root.get(), &s.bvh_full);
+        emit_device(s, root.get(), &s);
+    }
+    return MRT_OK;
+}
+
+}  // namespace mrt

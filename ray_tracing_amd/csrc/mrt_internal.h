@@ -1,0 +1,106 @@
+// mrt_internal.h -- flattened scene records shared by the host-side scene
+// builder (mrt_host.cpp) and the HIP kernels (mrt_device.hip).
+#ifndef MRT_INTERNAL_H
+#define MRT_INTERNAL_H
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mrt.h"
+
+namespace mrt {
+
+// Affine map p' = (a[0]*x + a[1]*y + a[2]*z) + a[3] per output row.
+struct Affine {
+    double r[3][4];
+};
+
+// Object = shape + Transform (cpu_rt/src/ray_tracer/hittable.rs:184-201) with
+// the matrices Object::hit recomputes per hit (hittable.rs:215-220) precomputed.
+struct DObject {
+    int32_t shape;
+    int32_t identity;    // 1: world_transform is the identity matrix
+    Affine to_object;    // world_transform
+    Affine to_world;     // world_transform^-1
+    double normal_m[3][3];  // (upper-left 3x3 of world_transform)^-1, rows
+};
+
+struct DShape {
+    int32_t kind;
+    int32_t material;
+    int32_t boundary;
+    int32_t octree;
+    double p[10];
+};
+
+struct DMaterial {
+    int32_t kind;
+    int32_t texture;
+    double fuzz;
+    double index_refraction;
+    float color[3];
+    int32_t pad;
+};
+
+struct DTexture {
+    int32_t kind, a, b, image;
+    float color[3];
+    int32_t pad;
+};
+
+struct DImage {
+    int32_t width, height;
+    uint64_t offset;  // float offset into the image pool
+};
+
+struct DOctree {
+    uint32_t root;
+    uint32_t world_log2;   // root size (log2 of the world edge)
+    uint32_t node_offset;  // offsets into the shared octree pools
+    uint32_t child_offset;
+    uint32_t voxel_offset;
+    uint32_t n_nodes;
+};
+
+// Camera::new output (camera.rs:44-76)
+struct DCamera {
+    double origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3];
+    double lens_radius, start_time, end_time;
+};
+
+// BVH node flags
+enum : int32_t {
+    NODE_DYNAMIC_BOX = 1,  // leaf whose box depends on (t_min, t_max): MovingSphere (bvh.rs:142-145,180)
+    NODE_TWICE = 2         // span-1 leaf pair folded into one node; evaluate the object twice (bvh.rs:224-232)
+};
+
+// Host-side flattened scene.
+struct FlatScene {
+    std::vector<DObject> objects, lights;
+    std::vector<DShape> shapes;
+    std::vector<DMaterial> materials;
+    std::vector<DTexture> textures;
+    std::vector<DImage> images;
+    std::vector<float> image_pool;
+    std::vector<DOctree> octrees;
+    std::vector<mrt_oct_node> oct_nodes;
+    std::vector<uint32_t> oct_children;
+    std::vector<mrt_voxel> oct_voxels;
+    DCamera camera;
+    mrt_background background;
+    mrt_sun sun;
+
+    // BVH in the reference's topology, pre-order (what mrt_scene_bvh exports)
+    std::vector<mrt_bvh_node> bvh_full;
+    // device BVH: duplicate leaves folded; SoA
+    std::vector<double> bmin[3], bmax[3];
+    std::vector<int32_t> node_object, node_skip, node_flags;
+    bool has_medium = false;
+};
+
+// Builds FlatScene from the descriptor. Returns an mrt_status; `err` receives a message.
+int flatten_scene(const mrt_scene_desc* desc, FlatScene* out, std::string* err);
+
+}  // namespace mrt
+#endif

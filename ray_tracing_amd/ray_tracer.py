@@ -1,0 +1,192 @@
+"""Host mirror of `RayTracer` / `ParallelImage` over the C ABI.
+
+Names follow the reference (cpu_rt/src/ray_tracer.rs:330-580,
+cpu_rt/src/parallel_image.rs:19-126,241-332): `trace_image` adds one sample per
+pixel, `tracing_loop` adds `num_samples`, `trace_part` works on one vertical
+strip. All pixel work happens in libmrt.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+
+from . import _ffi as F
+from .scene import WorldInfo
+
+
+class ParallelImage:
+    """f32 RGB accumulation image, index x + y*width, row y = 0 at the bottom (parallel_image.rs:19-24)."""
+
+    def __init__(self, buffer: np.ndarray):
+        assert buffer.dtype == np.float32 and buffer.ndim == 3 and buffer.shape[2] == 3
+        self.buffer = np.ascontiguousarray(buffer)
+
+    @staticmethod
+    def new_black(width: int, height: int) -> "ParallelImage":
+        return ParallelImage(np.zeros((height, width, 3), dtype=np.float32))
+
+    @property
+    def width(self) -> int:
+        return self.buffer.shape[1]
+
+    @property
+    def height(self) -> int:
+        return self.buffer.shape[0]
+
+    def get_xy(self, x: int, y: int) -> np.ndarray:
+        return self.buffer[y, x]
+
+    def __truediv__(self, rhs: float) -> "ParallelImage":  # parallel_image.rs:268-278
+        return ParallelImage(self.buffer / np.float32(rhs))
+
+    def split(self, num_parts: int) -> List["ParallelImagePart"]:
+        """Vertical strips of width // num_parts columns; the remainder columns are dropped
+        exactly as the reference does (parallel_image.rs:103-126)."""
+        slice_width = self.width // num_parts
+        parts = []
+        for s in range(num_parts):
+            start = slice_width * s
+            end = min(start + slice_width, self.width)
+            parts.append(ParallelImagePart(self, start, end - start))
+        return parts
+
+    def to_image(self, num_samples: int) -> np.ndarray:
+        """uint8 (height, width, 3), top row first (parallel_image.rs:35-65)."""
+        lib = F.load()
+        out = np.zeros((self.height, self.width, 3), dtype=np.uint8)
+        F.check(lib.mrt_to_image(self.buffer.ctypes.data, self.width, self.height, num_samples, out.ctypes.data))
+        return out
+
+
+@dataclass
+class ParallelImagePart:
+    """A vertical strip view: columns [offset_x, offset_x + width) of `image` (parallel_image.rs:279-332)."""
+    image: ParallelImage
+    offset_x: int
+    width: int
+
+    @property
+    def height(self) -> int:
+        return self.image.height
+
+    @property
+    def total_width(self) -> int:
+        return self.image.width
+
+
+@dataclass
+class RenderStats:
+    paths: int
+    rays: int
+    light_queries: int
+    launches: int
+    kernel_ms: float
+    total_ms: float
+    segment_kernel_avg_ms: float
+
+
+class World:
+    """Device-resident world: `WorldInfo::build_world` (world.rs:64-76) on the GPU."""
+
+    def __init__(self, info: WorldInfo, device: int = 0):
+        self._lib = F.load()
+        self._flat = info.flatten()
+        err = C.create_string_buffer(512)
+        self._handle = self._lib.mrt_scene_create(C.byref(self._flat.desc), device, err, len(err))
+        if not self._handle:
+            raise F.MrtError(F.MRT_ERR_INVALID_ARGUMENT, err.value.decode("utf-8", "replace"))
+        self.device = device
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            self._lib.mrt_scene_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._handle
+
+    def set_option(self, name: str, value: int) -> None:
+        F.check(self._lib.mrt_scene_set_option(self._handle, name.encode(), int(value)))
+
+    def bvh(self) -> np.ndarray:
+        n = C.c_size_t(0)
+        F.check(self._lib.mrt_scene_bvh(self._handle, None, 0, C.byref(n)))
+        nodes = (F.BvhNode * max(1, n.value))()
+        F.check(self._lib.mrt_scene_bvh(self._handle, nodes, n.value, C.byref(n)))
+        return np.array([(list(x.bmin), list(x.bmax), x.object, x.skip) for x in nodes[:n.value]],
+                        dtype=[("bmin", "f8", 3), ("bmax", "f8", 3), ("object", "i4"), ("skip", "i4")])
+
+    def camera_rays(self, width: int, height: int, pixels: np.ndarray, seed: int, sample_index: int) -> np.ndarray:
+        px = np.ascontiguousarray(pixels, dtype=np.int32).reshape(-1, 2)
+        out = np.zeros((len(px), 7), dtype=np.float64)
+        F.check(self._lib.mrt_camera_rays(self._handle, width, height, px.ctypes.data, len(px), seed, sample_index,
+                                          out.ctypes.data))
+        return out
+
+    def trace_rays(self, rays: np.ndarray, seed: int = 0):
+        r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 7)
+        n = len(r)
+        obj = np.zeros(n, dtype=np.int32)
+        t = np.zeros(n, dtype=np.float64)
+        normal = np.zeros((n, 3), dtype=np.float64)
+        pos = np.zeros((n, 3), dtype=np.float64)
+        ff = np.zeros(n, dtype=np.int32)
+        F.check(self._lib.mrt_trace_rays(self._handle, r.ctypes.data, n, seed, obj.ctypes.data, t.ctypes.data,
+                                         normal.ctypes.data, pos.ctypes.data, ff.ctypes.data))
+        return obj, t, normal, pos, ff
+
+
+def _stats(s: F.Stats) -> RenderStats:
+    return RenderStats(s.paths, s.rays, s.light_queries, s.launches, s.kernel_ms, s.total_ms, s.segment_kernel_avg_ms)
+
+
+class RayTracer:
+    """`RayTracer` with `CurrentShader::Raytracing` (ray_tracer.rs:330-336)."""
+
+    def __init__(self, info: WorldInfo, device: int = 0, seed: int = 0):
+        self.world = World(info, device)
+        self.seed = seed
+        self._next_sample = 0
+        self._lib = F.load()
+        self.last_stats: Optional[RenderStats] = None
+
+    def trace_part(self, part: ParallelImagePart, num_samples: int = 1, first_sample: Optional[int] = None) -> RenderStats:
+        """`num_samples` x trace_part (ray_tracer.rs:435-463) over the strip, accumulated into part.image."""
+        img = part.image
+        fs = self._next_sample if first_sample is None else first_sample
+        st = F.Stats()
+        F.check(self._lib.mrt_render_accumulate(self.world.handle, img.buffer.ctypes.data, img.width, img.height,
+                                                part.offset_x, part.width, num_samples, self.seed, fs, C.byref(st)))
+        self.last_stats = _stats(st)
+        return self.last_stats
+
+    def trace_image(self, rgb_img: ParallelImage) -> RenderStats:  # ray_tracer.rs:413-418
+        st = self.trace_part(rgb_img.split(1)[0], 1)
+        self._next_sample += 1
+        return st
+
+    def tracing_loop(self, parallel_image: ParallelImage, num_samples: int) -> ParallelImage:
+        """ray_tracer.rs:469-477 without the bloom post-process: returns accumulation / num_samples."""
+        self.trace_part(parallel_image.split(1)[0], num_samples)
+        self._next_sample += num_samples
+        return parallel_image / float(num_samples)
+
+    def render_device(self, accum_ptr: int, width: int, height: int, spp: int, first_sample: int = 0,
+                      x0: int = 0, strip_w: Optional[int] = None, stream: int = 0) -> RenderStats:
+        """Accumulates into a device-resident f32 buffer (e.g. a torch tensor's data_ptr())."""
+        st = F.Stats()
+        sw = width - x0 if strip_w is None else strip_w
+        F.check(self._lib.mrt_render_accumulate_device(self.world.handle, accum_ptr, width, height, x0, sw, spp,
+                                                       self.seed, first_sample, stream, C.byref(st)))
+        self.last_stats = _stats(st)
+        return self.last_stats

@@ -1,0 +1,157 @@
+"""Scene constants of the reference's scenario constructors, as inputs.
+
+Each function returns the `WorldInfo` that the reference's function of the same
+name builds (cpu_rt/src/ray_tracer/world/*.rs); the reference registers them by
+display name in `get_scenarios` (cpu_rt/src/ray_tracer/world.rs:153-269).
+Where the reference draws scene parameters from its unseeded global RNG
+(random_scene.rs:63-123), a seeded numpy generator is used instead.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, Optional
+
+import numpy as np
+
+from .scene import (CameraInfo, ConstantColor, ConstantMedium, Dielectric, DiffuseLight, ImageTexture, Isotropic,
+                    Lambertian, Metal, MovingSphere, MultiplyTexture, Object, RenderBox, Sky, SolidColor, Sphere,
+                    Transform, WorldInfo, XYRect, XZRect, YZRect)
+
+
+def _dist(a, b) -> float:
+    t = [a[i] - b[i] for i in range(3)]
+    return math.sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2])
+
+
+def cornell_smoke() -> WorldInfo:
+    """world/cornell_smoke.rs:11-159. Note flip=False on the green wall, ceiling and back wall."""
+    look_at, origin = (278.0, 278.0, 0.0), (278.0, 278.0, -800.0)
+    green = Lambertian(SolidColor((0.12, 0.45, 0.15)))
+    red = Lambertian(SolidColor((0.65, 0.05, 0.05)))
+    light = DiffuseLight(SolidColor((7.0, 7.0, 7.0)))
+    white = Lambertian(SolidColor((0.73, 0.73, 0.73)))
+    top_light = Object(XZRect(113.0, 443.0, 127.0, 423.0, 554.0, light, True), Transform.identity())
+    objects = [
+        Object(YZRect(0.0, 555.0, 0.0, 555.0, 555.0, green, False)),
+        Object(YZRect(0.0, 555.0, 0.0, 555.0, 0.0, red, False)),
+        top_light,
+        Object(XZRect(0.0, 555.0, 0.0, 555.0, 0.0, white, False)),
+        Object(XZRect(0.0, 555.0, 0.0, 555.0, 555.0, white, False)),
+        Object(XYRect(0.0, 555.0, 0.0, 555.0, 555.0, white, False)),
+        Object(ConstantMedium(RenderBox((0.0, 0.0, 0.0), (165.0, 330.0, 165.0), white),
+                              Isotropic(SolidColor((0.0, 0.0, 0.0))), 0.01),
+               Transform.identity().translate((265.0, 0.0, 295.0))),
+        Object(ConstantMedium(Sphere(100.0, (0.0, 0.0, 0.0), white), Isotropic(SolidColor((0.5, 0.0, 0.0))), 0.01),
+               Transform.identity().translate((265.0, 500.0, 295.0))),
+        Object(RenderBox((0.0, 0.0, 0.0), (165.0, 165.0, 165.0), white),
+               Transform.identity().rotate_y(-18.0).translate((130.0, 0.0, 65.0))),
+    ]
+    return WorldInfo(
+        objects=objects,
+        lights=[Object(top_light.shape, Transform.identity())],
+        background=ConstantColor((0.0, 0.0, 0.0)),
+        camera=CameraInfo(1.0, 40.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0),
+        sun=None,
+    )
+
+
+def easy_cornell_box() -> WorldInfo:
+    """world/easy_cornell_box.rs."""
+    look_at, origin = (278.0, 278.0, 0.0), (278.0, 278.0, -800.0)
+    green = Lambertian(SolidColor((0.12, 0.45, 0.15)))
+    red = Lambertian(SolidColor((0.65, 0.05, 0.05)))
+    light = DiffuseLight(SolidColor((15.0, 15.0, 15.0)))
+    white = Lambertian(SolidColor((0.73, 0.73, 0.73)))
+    top_light = Object(XZRect(213.0, 343.0, 227.0, 332.0, 554.0, light, True))
+    objects = [
+        Object(YZRect(0.0, 555.0, 0.0, 555.0, 555.0, green, True)),
+        Object(YZRect(0.0, 555.0, 0.0, 555.0, 0.0, red, False)),
+        Object(XZRect(0.0, 555.0, 0.0, 555.0, 0.0, white, False)),
+        Object(XZRect(0.0, 555.0, 0.0, 555.0, 555.0, white, True)),
+        Object(XYRect(0.0, 555.0, 0.0, 555.0, 555.0, white, True)),
+        top_light,
+    ]
+    return WorldInfo(objects, [Object(top_light.shape)], ConstantColor((0.0, 0.0, 0.0)),
+                     CameraInfo(1.0, 40.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
+def one_sphere() -> WorldInfo:
+    """world/one_sphere.rs (the reference's default scenario)."""
+    look_at, origin = (0.0, 0.0, -1.0), (3.0, 3.0, 2.0)
+    return WorldInfo(
+        [Object(Sphere(0.5, (0.0, 0.0, -1.0), Lambertian(SolidColor((0.1, 0.2, 0.5)))))], [], Sky(1.0),
+        CameraInfo(1.0, 20.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
+def two_spheres() -> WorldInfo:
+    """world/two_spheres.rs."""
+    look_at, origin = (0.0, 0.0, -1.0), (3.0, 3.0, 2.0)
+    return WorldInfo(
+        [Object(Sphere(0.5, (0.0, 0.0, -1.0), Lambertian(SolidColor((0.1, 0.2, 0.5))))),
+         Object(Sphere(0.5, (1.0, 0.0, -1.0), Metal(SolidColor((0.8, 0.6, 0.2)), 0.0)))], [], Sky(1.0),
+        CameraInfo(1.0, 20.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
+def random_scene(seed: int = 1) -> WorldInfo:
+    """world/random_scene.rs:8-142: 22x22 grid of small spheres followed by the four big ones."""
+    rng = np.random.default_rng(seed)
+    r = lambda: float(rng.random())
+    rf32 = lambda: float(np.float32(rng.random(dtype=np.float32)))
+    objects = []
+    for a in range(-11, 11):
+        for b in range(-11, 11):
+            choose_mat = r()
+            center = (a + 0.9 * r(), 0.2, b + 0.9 * r())
+            if _dist(center, (4.0, 0.2, 0.0)) > 0.9:
+                if choose_mat < 0.8:
+                    c1 = (center[0], center[1] + r() * 0.5, center[2])
+                    objects.append(Object(MovingSphere(center, c1, 0.0, 1.0, 0.2,
+                                                       Lambertian(SolidColor((rf32(), rf32(), rf32()))))))
+                elif choose_mat < 0.95:
+                    albedo = SolidColor((rf32(), rf32(), rf32()))
+                    objects.append(Object(Sphere(0.2, center, Metal(albedo, r() * 0.5 + 0.5))))
+                else:
+                    objects.append(Object(Sphere(0.2, center, Dielectric(1.5, (1.0, 1.0, 1.0)))))
+    objects += [
+        Object(Sphere(1000.0, (0.0, -1000.0, 1000.0), Lambertian(SolidColor((0.5, 0.5, 0.5))))),
+        Object(Sphere(1.0, (0.0, 1.0, 0.0), Dielectric(1.5, (1.0, 1.0, 1.0)))),
+        Object(Sphere(1.0, (-4.0, 1.0, 0.0), Lambertian(SolidColor((0.4, 0.2, 0.1))))),
+        Object(Sphere(1.0, (4.0, 1.0, 0.0), Metal(SolidColor((0.4, 0.2, 0.1)), 0.0))),
+    ]
+    return WorldInfo(objects, [], Sky(1.0),
+                     CameraInfo(1.0, 20.0, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 0.0005, 10.0, 0.0, 0.0))
+
+
+def light_demo(earthmap: np.ndarray) -> WorldInfo:
+    """world/light_demo.rs ("Light Demonstration"). `earthmap`: float32 (H, W, 3) decode of assets/earthmap.jpg."""
+    look_at, origin = (0.0, 1.0, 0.0), (10.0, 10.0, 2.0)
+    floor = Object(XZRect(-5.0, 5.0, -5.0, 5.0, 0.0, Lambertian(SolidColor((0.5, 0.5, 0.5))), False))
+    l_sphere = Object(Sphere(1.0, (0.0, 1.0, 0.0), Metal(SolidColor((0.5, 0.1, 0.0)), 0.01)))
+    light = Object(Sphere(0.2, (0.0, 3.0, 1.0),
+                          DiffuseLight(MultiplyTexture(ImageTexture(earthmap), SolidColor((100.0, 100.0, 100.0))))))
+    return WorldInfo([floor, light, l_sphere], [Object(light.shape)], Sky(0.3),
+                     CameraInfo(1.0, 20.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
+def synthetic_earthmap(width: int = 256, height: int = 128) -> np.ndarray:
+    """A deterministic stand-in for assets/earthmap.jpg with u8/255 texel values."""
+    y, x = np.mgrid[0:height, 0:width]
+    r = ((x * 7 + y * 3) % 256).astype(np.float32) / np.float32(255.0)
+    g = ((x * 2 + y * 11) % 256).astype(np.float32) / np.float32(255.0)
+    b = ((x ^ y) % 256).astype(np.float32) / np.float32(255.0)
+    return np.stack([r, g, b], axis=-1).astype(np.float32)
+
+
+SCENARIOS: Dict[str, Callable[[], WorldInfo]] = {
+    "Cornell Smoke": cornell_smoke,
+    "Easy Cornell Box": easy_cornell_box,
+    "One Sphere": one_sphere,
+    "Two Sphere": two_spheres,
+    "Random Scene": random_scene,
+}
+
+
+def build(name: str, earthmap: Optional[np.ndarray] = None) -> WorldInfo:
+    if name == "Light Demonstration":
+        return light_demo(earthmap if earthmap is not None else synthetic_earthmap())
+    return SCENARIOS[name]()

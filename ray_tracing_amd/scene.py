@@ -1,0 +1,428 @@
+"""Host-side mirror of the reference's scene API, flattened into the C ABI.
+
+The classes carry the names and argument meaning of the reference's types
+(cpu_rt/src/ray_tracer/{hittable,material,texture,camera,world}.rs and
+hittable/*.rs) so that scenes read like the reference's scenario constructors.
+`WorldInfo.flatten()` produces the plain-old-data `mrt_scene_desc` that
+`mrt_scene_create` (and the CPU checker) consume; nothing here computes pixels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _ffi as F
+
+Vec3 = Tuple[float, float, float]
+
+
+# ------------------------------------------------------------------ textures (texture.rs)
+class Texture:
+    pass
+
+
+@dataclass
+class SolidColor(Texture):
+    color: Vec3
+
+
+@dataclass
+class ImageTexture(Texture):
+    """pixels: float32 array (height, width, 3) in [0,1], row 0 = top (texture.rs:196-215)."""
+    pixels: np.ndarray
+
+
+@dataclass
+class MultiplyTexture(Texture):
+    a: Texture
+    b: Texture
+
+
+@dataclass
+class CheckerTexture(Texture):
+    odd: Texture
+    even: Texture
+
+
+@dataclass
+class DebugV(Texture):
+    pass
+
+
+# ------------------------------------------------------------------ materials (material.rs)
+class Material:
+    pass
+
+
+@dataclass
+class Lambertian(Material):
+    albedo: Texture
+
+
+@dataclass
+class Metal(Material):
+    albedo: Texture
+    fuzz: float
+
+
+@dataclass
+class Dielectric(Material):
+    index_refraction: float
+    color: Vec3
+
+
+@dataclass
+class DiffuseLight(Material):
+    emit: Texture
+
+
+@dataclass
+class Isotropic(Material):
+    albedo: Texture
+
+
+# ------------------------------------------------------------------ shapes (hittable/*.rs)
+class Hittable:
+    pass
+
+
+@dataclass
+class Sphere(Hittable):
+    radius: float
+    origin: Vec3
+    material: Material
+
+
+@dataclass
+class MovingSphere(Hittable):
+    center_0: Vec3
+    center_1: Vec3
+    time_0: float
+    time_1: float
+    radius: float
+    material: Material
+
+
+@dataclass
+class XYRect(Hittable):
+    x0: float
+    x1: float
+    y0: float
+    y1: float
+    k: float
+    material: Material
+    flip_normals: bool
+
+
+@dataclass
+class XZRect(Hittable):
+    x0: float
+    x1: float
+    z0: float
+    z1: float
+    k: float
+    material: Material
+    flip_normals: bool
+
+
+@dataclass
+class YZRect(Hittable):
+    y0: float
+    y1: float
+    z0: float
+    z1: float
+    k: float
+    material: Material
+    flip_normals: bool
+
+
+@dataclass
+class RenderBox(Hittable):
+    box_min: Vec3
+    box_max: Vec3
+    material: Material
+
+
+@dataclass
+class ConstantMedium(Hittable):
+    boundary: Hittable
+    phase_function: Material
+    density: float
+
+
+@dataclass
+class VoxelGrid(Hittable):
+    """Linearised FastOctTree<Voxel>: see ray_tracing_amd.octree.OctTree.linearise()."""
+    nodes: np.ndarray      # structured (kind i4, size u4, first_child i4, voxel i4)
+    children: np.ndarray   # uint32, 8 per parent
+    voxels: np.ndarray     # float32 (n, 3) Lambertian albedo per distinct voxel
+    root: int
+
+
+# ------------------------------------------------------------------ Transform (hittable.rs:64-122)
+def _mat_mul(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    return a @ b
+
+
+@dataclass
+class Transform:
+    """world_transform as a 4x4 row-major numpy matrix acting on column vectors (world -> object)."""
+    world_transform: np.ndarray = field(default_factory=lambda: np.eye(4))
+
+    @staticmethod
+    def identity() -> "Transform":
+        return Transform(np.eye(4))
+
+    def translate(self, t: Vec3) -> "Transform":  # hittable.rs:83-85: self * from_translation(-t)
+        m = np.eye(4)
+        m[0, 3], m[1, 3], m[2, 3] = -1.0 * t[0], -1.0 * t[1], -1.0 * t[2]
+        return Transform(_mat_mul(self.world_transform, m))
+
+    def rotate_x(self, deg: float) -> "Transform":  # cgmath from_angle_x
+        s, c = math.sin(deg * math.pi / 180.0), math.cos(deg * math.pi / 180.0)
+        m = np.eye(4)
+        m[1, 1], m[2, 1], m[1, 2], m[2, 2] = c, s, -s, c
+        return Transform(_mat_mul(self.world_transform, m))
+
+    def rotate_y(self, deg: float) -> "Transform":  # cgmath from_angle_y: x' = c x + s z, z' = -s x + c z
+        s, c = math.sin(deg * math.pi / 180.0), math.cos(deg * math.pi / 180.0)
+        m = np.eye(4)
+        m[0, 0], m[2, 0], m[0, 2], m[2, 2] = c, -s, s, c
+        return Transform(_mat_mul(self.world_transform, m))
+
+
+@dataclass
+class Object:
+    shape: Hittable
+    transform: Transform = field(default_factory=Transform.identity)
+
+
+# ------------------------------------------------------------------ camera / background / sun
+@dataclass
+class CameraInfo:  # camera.rs:14-24
+    aspect_ratio: float
+    fov: float
+    origin: Vec3
+    look_at: Vec3
+    up_vector: Vec3
+    aperture: float
+    focus_distance: float
+    start_time: float
+    end_time: float
+
+
+class Background:
+    pass
+
+
+@dataclass
+class Sky(Background):
+    intensity: float = 1.0
+
+
+@dataclass
+class SunSky(Background):
+    intensity: float
+    sun_radius: float
+    sun_theta: float
+    sun_phi: float
+    sun_brightness: float
+
+
+@dataclass
+class ConstantColor(Background):
+    color: Vec3
+
+
+@dataclass
+class Sun:  # sun.rs:10-15
+    phi: float
+    theta: float
+    radius: float
+
+
+# ------------------------------------------------------------------ WorldInfo (world.rs:56-62)
+class FlatDesc:
+    """Owns the ctypes arrays behind an mrt_scene_desc (keeps them alive)."""
+
+    def __init__(self):
+        self.desc = F.SceneDesc()
+        self.keep: list = []
+
+
+@dataclass
+class WorldInfo:
+    objects: List[Object]
+    lights: List[Object]
+    background: Background
+    camera: CameraInfo
+    sun: Optional[Sun] = None
+    bvh_seed: int = 0
+
+    def flatten(self) -> FlatDesc:
+        textures: List[F.Texture] = []
+        images: List[F.Image] = []
+        materials: List[F.Material] = []
+        shapes: List[F.Shape] = []
+        octrees: List[F.Octree] = []
+        out = FlatDesc()
+        tex_ids, mat_ids, shape_ids = {}, {}, {}
+
+        def add_texture(t: Texture) -> int:
+            if id(t) in tex_ids:
+                return tex_ids[id(t)]
+            rec = F.Texture()
+            rec.a = rec.b = rec.image = -1
+            if isinstance(t, SolidColor):
+                rec.kind = F.TEX_SOLID
+                rec.color[:] = [float(np.float32(c)) for c in t.color]
+            elif isinstance(t, ImageTexture):
+                px = np.ascontiguousarray(t.pixels, dtype=np.float32)
+                assert px.ndim == 3 and px.shape[2] == 3
+                out.keep.append(px)
+                img = F.Image(px.shape[1], px.shape[0], px.ctypes.data_as(C.POINTER(C.c_float)))
+                images.append(img)
+                rec.kind = F.TEX_IMAGE
+                rec.image = len(images) - 1
+            elif isinstance(t, MultiplyTexture):
+                rec.kind = F.TEX_MULTIPLY
+                rec.a, rec.b = add_texture(t.a), add_texture(t.b)
+            elif isinstance(t, CheckerTexture):
+                rec.kind = F.TEX_CHECKER
+                rec.a, rec.b = add_texture(t.odd), add_texture(t.even)
+            elif isinstance(t, DebugV):
+                rec.kind = F.TEX_DEBUG_V
+            else:
+                raise TypeError(f"unsupported texture {type(t).__name__}")
+            textures.append(rec)
+            tex_ids[id(t)] = len(textures) - 1
+            return tex_ids[id(t)]
+
+        def add_material(m: Material) -> int:
+            if id(m) in mat_ids:
+                return mat_ids[id(m)]
+            rec = F.Material()
+            rec.texture = -1
+            if isinstance(m, Lambertian):
+                rec.kind, rec.texture = F.MAT_LAMBERTIAN, add_texture(m.albedo)
+            elif isinstance(m, Metal):
+                rec.kind, rec.texture, rec.fuzz = F.MAT_METAL, add_texture(m.albedo), float(m.fuzz)
+            elif isinstance(m, Dielectric):
+                rec.kind, rec.index_refraction = F.MAT_DIELECTRIC, float(m.index_refraction)
+                rec.color[:] = [float(np.float32(c)) for c in m.color]
+            elif isinstance(m, DiffuseLight):
+                rec.kind, rec.texture = F.MAT_DIFFUSE_LIGHT, add_texture(m.emit)
+            elif isinstance(m, Isotropic):
+                rec.kind, rec.texture = F.MAT_ISOTROPIC, add_texture(m.albedo)
+            else:
+                raise TypeError(f"unsupported material {type(m).__name__}")
+            materials.append(rec)
+            mat_ids[id(m)] = len(materials) - 1
+            return mat_ids[id(m)]
+
+        def add_shape(s: Hittable) -> int:
+            if id(s) in shape_ids:
+                return shape_ids[id(s)]
+            rec = F.Shape()
+            rec.material = rec.boundary = rec.octree = -1
+            p = [0.0] * 10
+            if isinstance(s, Sphere):
+                rec.kind, rec.material = F.SHAPE_SPHERE, add_material(s.material)
+                p[0], p[1:4] = s.radius, s.origin
+            elif isinstance(s, MovingSphere):
+                rec.kind, rec.material = F.SHAPE_MOVING_SPHERE, add_material(s.material)
+                p[0], p[1:4], p[4:7], p[7], p[8] = s.radius, s.center_0, s.center_1, s.time_0, s.time_1
+            elif isinstance(s, XYRect):
+                rec.kind, rec.material = F.SHAPE_XY_RECT, add_material(s.material)
+                p[0:6] = [s.x0, s.x1, s.y0, s.y1, s.k, -1.0 if s.flip_normals else 1.0]
+            elif isinstance(s, XZRect):
+                rec.kind, rec.material = F.SHAPE_XZ_RECT, add_material(s.material)
+                p[0:6] = [s.x0, s.x1, s.z0, s.z1, s.k, -1.0 if s.flip_normals else 1.0]
+            elif isinstance(s, YZRect):
+                rec.kind, rec.material = F.SHAPE_YZ_RECT, add_material(s.material)
+                p[0:6] = [s.y0, s.y1, s.z0, s.z1, s.k, -1.0 if s.flip_normals else 1.0]
+            elif isinstance(s, RenderBox):
+                rec.kind, rec.material = F.SHAPE_RENDER_BOX, add_material(s.material)
+                p[0:3], p[3:6] = s.box_min, s.box_max
+            elif isinstance(s, ConstantMedium):
+                b = add_shape(s.boundary)
+                rec.kind, rec.material, rec.boundary = F.SHAPE_CONSTANT_MEDIUM, add_material(s.phase_function), b
+                p[0] = s.density
+            elif isinstance(s, VoxelGrid):
+                nodes = np.ascontiguousarray(s.nodes)
+                children = np.ascontiguousarray(s.children, dtype=np.uint32)
+                vox = np.zeros(len(s.voxels), dtype=np.dtype([("kind", "<i4"), ("albedo", "<f4", 3), ("fuzz", "<f4"),
+                                                              ("reserved", "<i4", 3)]))
+                vox["albedo"] = np.asarray(s.voxels, dtype=np.float32).reshape(-1, 3)
+                out.keep += [nodes, children, vox]
+                o = F.Octree()
+                o.root, o.n_nodes = int(s.root), len(nodes)
+                o.nodes = C.cast(nodes.ctypes.data, C.POINTER(F.OctNode))
+                o.n_children = len(children)
+                o.children = C.cast(children.ctypes.data, C.POINTER(C.c_uint32))
+                o.n_voxels = len(vox)
+                o.voxels = C.cast(vox.ctypes.data, C.POINTER(F.Voxel))
+                octrees.append(o)
+                rec.kind, rec.octree = F.SHAPE_OCTREE, len(octrees) - 1
+            else:
+                raise TypeError(f"unsupported shape {type(s).__name__}")
+            rec.p[:] = [float(v) for v in p]
+            shapes.append(rec)
+            shape_ids[id(s)] = len(shapes) - 1
+            return shape_ids[id(s)]
+
+        def mk_objects(objs: Sequence[Object]):
+            arr = (F.Object * max(1, len(objs)))()
+            for i, o in enumerate(objs):
+                arr[i].shape = add_shape(o.shape)
+                m = np.asarray(o.transform.world_transform, dtype=np.float64)
+                # column-major as cgmath stores it: element (row r, col c) at [c*4 + r]
+                arr[i].world_transform[:] = [float(m[r, c]) for c in range(4) for r in range(4)]
+            return arr
+
+        objs = mk_objects(self.objects)
+        lights = mk_objects(self.lights)
+
+        def arr_of(ctype, items):
+            a = (ctype * max(1, len(items)))()
+            for i, it in enumerate(items):
+                a[i] = it
+            return a
+
+        d = out.desc
+        d.abi_version = F.MRT_ABI_VERSION
+        ta, ia, ma, sa, oa = (arr_of(F.Texture, textures), arr_of(F.Image, images), arr_of(F.Material, materials),
+                              arr_of(F.Shape, shapes), arr_of(F.Octree, octrees))
+        out.keep += [ta, ia, ma, sa, oa, objs, lights]
+        d.n_textures, d.textures = len(textures), ta
+        d.n_images, d.images = len(images), ia
+        d.n_materials, d.materials = len(materials), ma
+        d.n_shapes, d.shapes = len(shapes), sa
+        d.n_octrees, d.octrees = len(octrees), oa
+        d.n_objects, d.objects = len(self.objects), objs
+        d.n_lights, d.lights = len(self.lights), lights
+        c = self.camera
+        d.camera.aspect_ratio, d.camera.fov = c.aspect_ratio, c.fov
+        d.camera.origin[:], d.camera.look_at[:], d.camera.up_vector[:] = c.origin, c.look_at, c.up_vector
+        d.camera.aperture, d.camera.focus_distance = c.aperture, c.focus_distance
+        d.camera.start_time, d.camera.end_time = c.start_time, c.end_time
+        b = self.background
+        if isinstance(b, Sky):
+            d.background.kind, d.background.intensity = F.BG_SKY, b.intensity
+        elif isinstance(b, SunSky):
+            d.background.kind, d.background.intensity = F.BG_SUN_SKY, b.intensity
+            d.background.sun_radius, d.background.sun_theta = b.sun_radius, b.sun_theta
+            d.background.sun_phi, d.background.sun_brightness = b.sun_phi, b.sun_brightness
+        elif isinstance(b, ConstantColor):
+            d.background.kind = F.BG_CONSTANT
+            d.background.color[:] = [float(np.float32(v)) for v in b.color]
+        else:
+            raise TypeError("unsupported background")
+        if self.sun is not None:
+            d.sun.has_sun, d.sun.phi, d.sun.theta, d.sun.radius = 1, self.sun.phi, self.sun.theta, self.sun.radius
+        d.bvh_seed = self.bvh_seed
+        return out
