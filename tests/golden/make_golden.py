@@ -1,0 +1,57 @@
+"""Generates the committed golden vectors from the CPU checker (oracle/libmrt_oracle.so).
+
+Run from the repository root:  python tests/golden/make_golden.py
+The reference itself is Rust and cannot be executed here, so these vectors pin the checker's
+behaviour (regression) and give the GPU tests fixed inputs/outputs that travel with the repo.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from ray_tracing_amd import scenarios  # noqa: E402
+from ray_tracing_amd.scene import (CameraInfo, Lambertian, Object, Sky, SolidColor, Sphere, WorldInfo)  # noqa: E402
+from tests import oracle_ffi  # noqa: E402
+from tests.helpers import line_of_spheres, probe_rays, scene_by_name  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    lib = oracle_ffi.load()
+    # 1. RNG known answers
+    kat = []
+    for seed, pixel, sample, seg, dim in [(0, 0, 0, 0, 0), (1, 2, 3, 4, 5), (7, 2073599, 1023, 49, 0x1000),
+                                          (2**63 + 12345, 8294399, 16383, 17, 0x2FF), (42, 100, 0, 1, 0x100)]:
+        kat.append({"seed": seed, "pixel": pixel, "sample": sample, "seg": seg, "dim": dim,
+                    "u64": int(lib.oracle_rng_u64(seed, pixel, sample, seg, dim))})
+    json.dump(kat, open(os.path.join(OUT, "rng_kat.json"), "w"), indent=1)
+
+    # 2. BVH topology tables, n = 1..16 objects, seeds 0..3
+    topo = {}
+    for n in range(1, 17):
+        for seed in range(4):
+            info = line_of_spheres(n, seed)
+            b = oracle_ffi.OracleWorld(info).bvh()
+            topo[f"{n}:{seed}"] = {"object": b["object"].tolist(), "skip": b["skip"].tolist()}
+    json.dump(topo, open(os.path.join(OUT, "bvh_topology.json"), "w"))
+
+    # 3. fixed rays -> nearest hit, and small renders, per scene
+    for name in ["Cornell Smoke", "Random Scene", "Light Demonstration", "Easy Cornell Box", "Two Sphere"]:
+        info = scene_by_name(name)
+        ow = oracle_ffi.OracleWorld(info)
+        rays = probe_rays(ow, info, n_camera=2048, n_random=2048, seed=5)
+        obj, t, normal, pos, ff = ow.trace_rays(rays, seed=11)
+        img, st = ow.render(32, 32, 8, seed=3, threads=4)
+        key = name.lower().replace(" ", "_")
+        np.savez_compressed(os.path.join(OUT, f"{key}.npz"), rays=rays, obj=obj, t=t, normal=normal, pos=pos, ff=ff,
+                            image_32x32_spp8_seed3=img, rays_traced=np.int64(st.rays),
+                            light_queries=np.int64(st.light_queries))
+        print(name, "hits", int((obj >= 0).sum()), "of", len(obj), "rays traced", st.rays)
+
+
+if __name__ == "__main__":
+    main()

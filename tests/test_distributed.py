@@ -1,0 +1,67 @@
+"""The N > 1 path: spp split across ranks + one all-reduce of the accumulation buffer, rehearsed
+with world_size 2 over gloo on CPU (the CPU checker stands in for the renderer here)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ray_tracing_amd import scenarios
+from ray_tracing_amd.distributed import render_sharded, sample_range
+
+
+def test_sample_ranges_partition():
+    for total in (0, 1, 7, 1024, 16384, 1027):
+        for n in (1, 2, 3, 4, 8):
+            ranges = [sample_range(total, r, n) for r in range(n)]
+            assert sum(c for _, c in ranges) == total
+            pos = 0
+            for first, count in ranges:
+                assert first == pos
+                pos += count
+            assert max(c for _, c in ranges) - min(c for _, c in ranges) <= 1
+    with pytest.raises(ValueError):
+        sample_range(8, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world_size, port, total_spp, out_path):
+    from tests.oracle_ffi import OracleWorld
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    W = H = 20
+    ow = OracleWorld(scenarios.cornell_smoke())
+    accum = torch.zeros((H, W, 3), dtype=torch.float32)
+    buf = accum.numpy()
+
+    def render(first, count):
+        ow.render(W, H, count, seed=4, first_sample=first, threads=2, accum=buf)
+
+    first, count = render_sharded(render, lambda: dist.all_reduce(accum), total_spp, rank, world_size)
+    assert (first, count) == sample_range(total_spp, rank, world_size)
+    if rank == 0:
+        np.save(out_path, accum.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_spp_split_equals_single_render(tmp_path):
+    from tests.oracle_ffi import OracleWorld
+    total_spp = 7
+    out = str(tmp_path / "sharded.npy")
+    mp.spawn(_worker, args=(2, _free_port(), total_spp, out), nprocs=2, join=True)
+    sharded = np.load(out)
+    single, _ = OracleWorld(scenarios.cornell_smoke()).render(20, 20, total_spp, seed=4, threads=2)
+    # same pixel-samples, different f32 summation order
+    np.testing.assert_allclose(sharded, single, rtol=1e-5, atol=1e-6)

@@ -1,0 +1,253 @@
+"""Parity of the HIP path (through the C ABI) with the CPU checker and the committed goldens.
+
+Tier A: nearest-hit queries on fixed rays -- object ids bit-exact, t / normals within 1e-5 relative
+        (north-star tolerance).
+Tier P: path level -- both sides address the same counter-based random numbers, so whole images
+        agree to f32 rounding except for rare discrete flips caused by 1-ulp differences in
+        transcendental functions / FMA contraction.
+Tier B: statistical -- RMSE(GPU, CPU independent estimator) <= 1.15 * RMSE(CPU, CPU') at equal spp,
+        channel means within 0.5 % (+ noise allowance).
+Full-size properties: union of sample ranges, strip independence, energy / mean consistency.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from ray_tracing_amd import ParallelImage, RayTracer, World, scenarios
+from tests import oracle_ffi
+from tests.helpers import probe_rays, rmse, scene_by_name
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SCENES = ["Cornell Smoke", "Random Scene", "Light Demonstration", "Easy Cornell Box", "Two Sphere"]
+T_RTOL = 1e-5      # north star: within 1e-5 relative hit t and normals
+N_ATOL = 1e-5
+
+
+def gpu_render(rt, w, h, spp, first=0, x0=0, strip_w=None, accum=None):
+    img = ParallelImage(accum) if accum is not None else ParallelImage.new_black(w, h)
+    part = img.split(1)[0]
+    part.offset_x, part.width = x0, (w - x0 if strip_w is None else strip_w)
+    st = rt.trace_part(part, spp, first_sample=first)
+    return img.buffer, st
+
+
+@pytest.fixture(scope="module")
+def worlds():
+    cache = {}
+
+    def get(name, seed=3):
+        if (name, seed) not in cache:
+            info = scene_by_name(name)
+            rt = RayTracer(info, device=0, seed=seed)
+            cache[(name, seed)] = (info, rt, oracle_ffi.OracleWorld(info))
+        return cache[(name, seed)]
+
+    return get
+
+
+def test_device_is_visible():
+    from ray_tracing_amd import _ffi
+    assert _ffi.load().mrt_device_count() >= 1
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_bvh_bit_exact(worlds, name):
+    info, rt, ow = worlds(name)
+    a, b = rt.world.bvh(), ow.bvh()
+    assert len(a) == len(b) and all((a[k] == b[k]).all() for k in a.dtype.names)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_camera_rays(worlds, name):
+    info, rt, ow = worlds(name)
+    W, H = 97, 61
+    ys, xs = np.mgrid[0:H, 0:W]
+    px = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
+    for sample in (0, 17):
+        a = rt.world.camera_rays(W, H, px, 9, sample)
+        b = ow.camera_rays(W, H, px, 9, sample)
+        scale = np.abs(b[:, 3:6]).max()
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, scale)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_tier_a_golden_rays(worlds, name):
+    """Committed fixed rays -> committed checker answers."""
+    info, rt, ow = worlds(name)
+    g = np.load(os.path.join(GOLD, name.lower().replace(" ", "_") + ".npz"))
+    obj, t, normal, pos, ff = rt.world.trace_rays(g["rays"], seed=11)
+    assert (obj == g["obj"]).all(), f"{int((obj != g['obj']).sum())} primary-hit ids differ"
+    hit = g["obj"] >= 0
+    np.testing.assert_allclose(t[hit], g["t"][hit], rtol=T_RTOL, atol=0)
+    np.testing.assert_allclose(normal[hit], g["normal"][hit], rtol=0, atol=N_ATOL)
+    np.testing.assert_allclose(pos[hit], g["pos"][hit], rtol=T_RTOL, atol=1e-6)
+    assert (ff[hit] == g["ff"][hit]).all()
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_tier_a_many_rays_vs_live_checker(worlds, name):
+    """>= 1e5 fixed rays per scene: camera rays plus random interior rays."""
+    info, rt, ow = worlds(name)
+    rays = probe_rays(ow, info, n_camera=60000, n_random=60000, seed=21)
+    og, tg, ng, pg, fg = rt.world.trace_rays(rays, seed=5)
+    oo, to, no, po, fo = ow.trace_rays(rays, seed=5)
+    assert (og == oo).all(), f"{int((og != oo).sum())} of {len(oo)} primary-hit ids differ"
+    hit = oo >= 0
+    assert hit.sum() > 1000
+    np.testing.assert_allclose(tg[hit], to[hit], rtol=T_RTOL, atol=0)
+    np.testing.assert_allclose(ng[hit], no[hit], rtol=0, atol=N_ATOL)
+    assert (fg[hit] == fo[hit]).all()
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_tier_p_golden_image(worlds, name):
+    info, rt, ow = worlds(name, seed=3)
+    g = np.load(os.path.join(GOLD, name.lower().replace(" ", "_") + ".npz"))
+    rt.world.set_option("trace_zero_throughput", 1)
+    img, st = gpu_render(rt, 32, 32, 8)
+    rt.world.set_option("trace_zero_throughput", 0)
+    ref = g["image_32x32_spp8_seed3"]
+    off = np.abs(img - ref).max(axis=2) > 1e-4 * np.maximum(1.0, np.abs(ref).max(axis=2))
+    assert off.sum() <= 3, f"{int(off.sum())} of 1024 pixels differ"
+    assert abs(st.rays - int(g["rays_traced"])) <= 8 and abs(st.light_queries - int(g["light_queries"])) <= 8
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_tier_p_image_vs_live_checker(worlds, name):
+    """Same seed, same sample indices: per-pixel agreement except rare discrete flips."""
+    info, rt, ow = worlds(name, seed=3)
+    W, H, spp = 160, 90, 16
+    rt.world.set_option("trace_zero_throughput", 1)
+    img, st = gpu_render(rt, W, H, spp, first=5)
+    rt.world.set_option("trace_zero_throughput", 0)
+    ref, rst = ow.render(W, H, spp, seed=3, first_sample=5, threads=16)
+    tol = 1e-4 * np.maximum(1.0, np.abs(ref).max(axis=2))
+    off = np.abs(img - ref).max(axis=2) > tol
+    assert off.mean() < 2e-3, f"{int(off.sum())} of {W * H} pixels differ"
+    assert abs(st.rays - rst.rays) <= max(8, rst.rays // 20000)
+    assert st.paths == rst.paths == W * H * spp
+    m_g, m_o = img.mean(axis=(0, 1)), ref.mean(axis=(0, 1))
+    np.testing.assert_allclose(m_g, m_o, rtol=2e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["Cornell Smoke", "Random Scene", "Light Demonstration"])
+def test_tier_b_statistical_rmse(worlds, name):
+    """RMSE protocol on linear pre-bloom radiance against an INDEPENDENT CPU estimator (mt19937_64)."""
+    info, rt, ow = worlds(name, seed=3)
+    W, H, spp = 96, 54, 256
+    img, _ = gpu_render(rt, W, H, spp)
+    cpu_a, _ = ow.render(W, H, spp, seed=100, threads=16, rng_mode=1)
+    cpu_b, _ = ow.render(W, H, spp, seed=200, threads=16, rng_mode=1)
+    g, a, b = img / spp, cpu_a / spp, cpu_b / spp
+    # display values clamp(sqrt(x)) (rgb_color.rs:75-80) damp fireflies
+    disp = lambda x: np.clip(np.sqrt(np.maximum(x, 0)), 0, 1)
+    r_cc, r_gc = rmse(disp(a), disp(b)), 0.5 * (rmse(disp(g), disp(a)) + rmse(disp(g), disp(b)))
+    assert r_gc <= 1.15 * r_cc, (r_gc, r_cc)
+    mg, mc = disp(g).mean(axis=(0, 1)), 0.5 * (disp(a).mean(axis=(0, 1)) + disp(b).mean(axis=(0, 1)))
+    noise = np.abs(disp(a).mean(axis=(0, 1)) - disp(b).mean(axis=(0, 1)))
+    assert (np.abs(mg - mc) <= 0.005 * mc + 2.0 * noise + 1e-4).all(), (mg, mc, noise)
+
+
+def test_cornell_rays_equal_checker_when_walking_zero_throughput_paths(worlds):
+    info, rt, ow = worlds("Cornell Smoke", seed=3)
+    rt.world.set_option("trace_zero_throughput", 1)
+    _, st1 = gpu_render(rt, 64, 64, 8)
+    rt.world.set_option("trace_zero_throughput", 0)
+    _, st0 = gpu_render(rt, 64, 64, 8)
+    _, rst = ow.render(64, 64, 8, seed=3, threads=8)
+    assert abs(st1.rays - rst.rays) <= 4
+    assert st0.rays <= st1.rays      # the black smoke (albedo 0) ends paths early, image unchanged
+
+
+def test_early_termination_does_not_change_the_image(worlds):
+    info, rt, ow = worlds("Cornell Smoke", seed=3)
+    rt.world.set_option("trace_zero_throughput", 1)
+    a, _ = gpu_render(rt, 64, 64, 8)
+    rt.world.set_option("trace_zero_throughput", 0)
+    b, _ = gpu_render(rt, 64, 64, 8)
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("opts", [dict(pool_slots=256, segments_per_launch=1), dict(pool_slots=4096, segments_per_launch=7),
+                                  dict(pool_slots=1 << 20, segments_per_launch=50), dict(compaction=0)])
+def test_scheduling_options_do_not_change_results(opts):
+    """Pool size / segments per launch / compaction only change the order of work."""
+    info = scenarios.cornell_smoke()
+    base = RayTracer(info, device=0, seed=12)
+    ref, rst = gpu_render(base, 80, 45, 6)
+    rt = RayTracer(info, device=0, seed=12)
+    for k, v in opts.items():
+        rt.world.set_option(k, v)
+    img, st = gpu_render(rt, 80, 45, 6)
+    assert st.rays == rst.rays and st.light_queries == rst.light_queries
+    np.testing.assert_allclose(img, ref, rtol=1e-5, atol=1e-6)   # f32 atomic adds: order-dependent last bits
+
+
+def test_strips_and_sample_ranges_compose(worlds):
+    """Ragged strips and split sample ranges reproduce the one-call render (trace_part semantics)."""
+    info, rt, ow = worlds("Cornell Smoke", seed=3)
+    W, H, spp = 83, 37, 5
+    whole, _ = gpu_render(rt, W, H, spp)
+    acc = np.zeros((H, W, 3), dtype=np.float32)
+    for x0, sw in [(0, 1), (1, 40), (41, 42)]:
+        gpu_render(rt, W, H, 2, first=0, x0=x0, strip_w=sw, accum=acc)
+        gpu_render(rt, W, H, 3, first=2, x0=x0, strip_w=sw, accum=acc)
+    np.testing.assert_allclose(acc, whole, rtol=1e-5, atol=1e-6)
+    # a strip render leaves the other columns untouched
+    acc2 = np.full((H, W, 3), 0.25, dtype=np.float32)
+    gpu_render(rt, W, H, 1, x0=10, strip_w=5, accum=acc2)
+    assert (acc2[:, :10] == 0.25).all() and (acc2[:, 15:] == 0.25).all()
+
+
+def test_zero_spp_and_bad_arguments(worlds):
+    from ray_tracing_amd import _ffi as F
+    info, rt, ow = worlds("Cornell Smoke", seed=3)
+    img, st = gpu_render(rt, 8, 8, 0)
+    assert (img == 0).all() and st.paths == 0
+    lib = F.load()
+    buf = np.zeros((8, 8, 3), dtype=np.float32)
+    assert lib.mrt_render_accumulate(rt.world.handle, buf.ctypes.data, 8, 8, 4, 5, 1, 0, 0, None) == F.MRT_ERR_INVALID_ARGUMENT
+    assert lib.mrt_render_accumulate(rt.world.handle, buf.ctypes.data, 1, 8, 0, 1, 1, 0, 0, None) == F.MRT_ERR_INVALID_ARGUMENT
+    assert lib.mrt_render_accumulate(rt.world.handle, None, 8, 8, 0, 8, 1, 0, 0, None) == F.MRT_ERR_INVALID_ARGUMENT
+
+
+def test_empty_world_renders_background():
+    from ray_tracing_amd.scene import CameraInfo, Sky, WorldInfo
+    info = WorldInfo([], [], Sky(1.0), CameraInfo(1.0, 40.0, (0, 0, 1), (0, 0, 0), (0, 1, 0), 0.0, 1.0, 0.0, 0.0))
+    rt = RayTracer(info, device=0, seed=0)
+    img, st = gpu_render(rt, 16, 16, 3)
+    ref, rst = oracle_ffi.OracleWorld(info).render(16, 16, 3, seed=0, threads=1)
+    assert st.rays == rst.rays == 16 * 16 * 3
+    np.testing.assert_allclose(img, ref, rtol=1e-6, atol=1e-6)
+
+
+def test_full_size_properties_1080p(worlds):
+    """BASELINE config size (1920x1080): properties that need no full-size CPU render."""
+    info, rt, ow = worlds("Cornell Smoke", seed=3)
+    W, H = 1920, 1080
+    a, sa = gpu_render(rt, W, H, 4, first=0)
+    # (1) union of sample ranges == one call
+    b, _ = gpu_render(rt, W, H, 1, first=0)
+    gpu_render(rt, W, H, 3, first=1, accum=b)
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+    # (2) every path is accounted for, segments per path is within the depth limit
+    assert sa.paths == W * H * 4 and sa.paths <= sa.rays <= 50 * sa.paths
+    # (3) radiance is bounded by the emitter (7,7,7) per sample and never negative / NaN
+    assert np.isfinite(a).all() and a.min() >= 0.0 and a.max() <= 7.0 * 4 * 1.0001
+    # (4) image statistics agree with a low-resolution checker render of the same scene
+    ref, _ = ow.render(240, 135, 32, seed=77, threads=16)
+    np.testing.assert_allclose(a.mean(axis=(0, 1)) / 4, ref.mean(axis=(0, 1)) / 32, rtol=0.03)
+    # (5) the quirk columns: green wall / back wall black at full resolution
+    assert a[400:700, 5:60].max() == 0.0 and a[500:560, 930:990].max() == 0.0
+
+
+def test_to_image_matches_checker(worlds, oracle):
+    info, rt, ow = worlds("Cornell Smoke", seed=3)
+    img, _ = gpu_render(rt, 64, 48, 4)
+    got = ParallelImage(img).to_image(4)
+    exp = np.zeros((48, 64, 3), dtype=np.uint8)
+    oracle.oracle_to_image(img.ctypes.data, 64, 48, 4, exp.ctypes.data)
+    assert (got == exp).all()

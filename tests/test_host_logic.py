@@ -1,0 +1,60 @@
+"""Host-side logic of the product library that needs no GPU: scene flattening and the BVH build
+(`BvhTree::new`, cpu_rt/src/ray_tracer/bvh.rs:78-96,206-293) against the CPU checker and the goldens."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ray_tracing_amd import World, scenarios
+from tests import oracle_ffi
+from tests.helpers import line_of_spheres, scene_by_name
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bvh_equal(a, b):
+    return len(a) == len(b) and all((a[k] == b[k]).all() for k in a.dtype.names)
+
+
+@pytest.mark.parametrize("name", ["Cornell Smoke", "Random Scene", "Light Demonstration", "Easy Cornell Box",
+                                  "One Sphere", "Two Sphere"])
+def test_bvh_matches_checker_bit_for_bit(name):
+    info = scene_by_name(name)
+    assert bvh_equal(World(info, device=-1).bvh(), oracle_ffi.OracleWorld(info).bvh())
+
+
+def test_bvh_topology_golden():
+    topo = json.load(open(os.path.join(GOLD, "bvh_topology.json")))
+    for key, exp in topo.items():
+        n, seed = (int(v) for v in key.split(":"))
+        b = World(line_of_spheres(n, seed), device=-1).bvh()
+        assert b["object"].tolist() == exp["object"] and b["skip"].tolist() == exp["skip"], key
+
+
+def test_bvh_seed_changes_only_pair_order():
+    a = World(line_of_spheres(9, 0), device=-1).bvh()
+    orders = set()
+    for seed in range(16):
+        b = World(line_of_spheres(9, seed), device=-1).bvh()
+        assert sorted(b["object"].tolist()) == sorted(a["object"].tolist())
+        orders.add(tuple(b["object"].tolist()))
+    assert len(orders) > 1   # bvh.rs:215-252: the random axis flips span-2 leaf order
+
+
+def test_empty_world_has_no_nodes():
+    from ray_tracing_amd.scene import WorldInfo, Sky, CameraInfo
+    info = WorldInfo([], [], Sky(1.0), CameraInfo(1.0, 40.0, (0, 0, 1), (0, 0, 0), (0, 1, 0), 0.0, 1.0, 0.0, 0.0))
+    assert len(World(info, device=-1).bvh()) == 0
+
+
+def test_transform_composition_matches_reference_order():
+    # hittable.rs:83-91: identity.rotate_y(-18).translate(130,0,65) = R_y(-18) * T(-130,0,-65)
+    from ray_tracing_amd.scene import Transform
+    m = Transform.identity().rotate_y(-18.0).translate((130.0, 0.0, 65.0)).world_transform
+    p = m @ np.array([130.0, 0.0, 65.0, 1.0])
+    np.testing.assert_allclose(p[:3], [0, 0, 0], atol=1e-12)       # the box corner maps to the object origin
+    q = m @ np.array([131.0, 0.0, 65.0, 1.0])
+    c, s = np.cos(np.radians(-18.0)), np.sin(np.radians(-18.0))
+    np.testing.assert_allclose(q[:3], [c, 0, -s], atol=1e-12)      # cgmath from_angle_y: x' = c x + s z, z' = -s x + c z
