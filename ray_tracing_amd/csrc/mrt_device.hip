@@ -99,8 +99,32 @@ __device__ __forceinline__ D3 cross(D3 a, D3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 __device__ __forceinline__ double magnitude(D3 a) { return sqrt(dot(a, a)); }
+// 1/x from v_rcp_f64 plus two Newton steps (about 1 ulp; an IEEE divide costs three times the
+// instructions). Zero, infinity and NaN keep the hardware result (inf, 0, NaN), which the slab
+// and plane tests rely on.
+__device__ __forceinline__ double rcp_fast(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    double r1 = fma(r, e, r);
+    e = fma(-x, r1, 1.0);
+    r1 = fma(r1, e, r1);
+    return (r1 == r1 && fabs(r) != INFINITY) ? r1 : r;
+}
+// 1/sqrt(x) from v_rsq_f64 plus two Newton steps, for x > 0 finite.
+__device__ __forceinline__ double rsqrt_fast(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double h = 0.5 * x;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
 // cgmath normalize: self * (1 / magnitude)
-__device__ __forceinline__ D3 normalize(D3 a) { return a * (1.0 / magnitude(a)); }
+__device__ __forceinline__ D3 normalize(D3 a) {
+    double d2 = dot(a, a);
+    double inv = (d2 > 1e-300 && d2 < 1e300) ? rsqrt_fast(d2) : 1.0 / sqrt(d2);
+    return a * inv;
+}
+constexpr double INV_PI = 0.31830988618379067154;
 __device__ __forceinline__ double comp(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 __device__ __forceinline__ D3 ld3(const double* p) { return {p[0], p[1], p[2]}; }
 
@@ -152,14 +176,25 @@ __device__ D3 rand_unit_vec(const Rng& g, uint32_t base) {
     return {0.0, 0.0, 0.0};
 }
 
+// Scene records are read through two kinds of pointers: ordinary global pointers when the
+// index differs per lane, and constant-address-space pointers (CONST_AS) when the index is the
+// same for the whole wave, so that the loads become scalar loads and the values live in SGPRs.
+#define CONST_AS __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const CONST_AS T* as_const(const T* p) {
+    return (const CONST_AS T*)p;
+}
+
 // ============================================================== transforms (hittable.rs:92-107)
-__device__ __forceinline__ D3 apply(const Affine& a, D3 p) {
-    return {((a.r[0][0] * p.x + a.r[0][1] * p.y) + a.r[0][2] * p.z) + a.r[0][3],
-            ((a.r[1][0] * p.x + a.r[1][1] * p.y) + a.r[1][2] * p.z) + a.r[1][3],
-            ((a.r[2][0] * p.x + a.r[2][1] * p.y) + a.r[2][2] * p.z) + a.r[2][3]};
+template <class AP>
+__device__ __forceinline__ D3 apply(AP a, D3 p) {
+    return {((a->r[0][0] * p.x + a->r[0][1] * p.y) + a->r[0][2] * p.z) + a->r[0][3],
+            ((a->r[1][0] * p.x + a->r[1][1] * p.y) + a->r[1][2] * p.z) + a->r[1][3],
+            ((a->r[2][0] * p.x + a->r[2][1] * p.y) + a->r[2][2] * p.z) + a->r[2][3]};
 }
 // Transform::mul_ray: direction = M*(o+d) - M*o; never renormalised, so t is shared.
-__device__ __forceinline__ RayD xform_ray(const Affine& a, bool identity, const RayD& r) {
+template <class AP>
+__device__ __forceinline__ RayD xform_ray(AP a, bool identity, const RayD& r) {
     if (identity) return {r.o, (r.o + r.d) - r.o, r.time};
     D3 e = apply(a, r.o + r.d);
     D3 o = apply(a, r.o);
@@ -167,13 +202,14 @@ __device__ __forceinline__ RayD xform_ray(const Affine& a, bool identity, const 
 }
 
 // ============================================================== shape intersection
-// rect.rs:63-86,185-206,309-331. AXIS = constant axis (2 XY, 1 XZ, 0 YZ).
+// rect.rs:63-86,185-206,309-331. AXIS = constant axis (2 XY, 1 XZ, 0 YZ). `inv` = 1/direction
+// per component, shared by every plane test against the same ray.
 template <int AXIS>
-__device__ __forceinline__ bool rect_hit(double a0, double a1, double b0, double b1, double k, const RayD& r,
+__device__ __forceinline__ bool rect_hit(double a0, double a1, double b0, double b1, double k, const RayD& r, D3 inv,
                                          double t_min, double t_max, double& t_out) {
     constexpr int IA = AXIS == 0 ? 1 : 0;
     constexpr int IB = AXIS == 2 ? 1 : 2;
-    double t = (k - comp(r.o, AXIS)) / comp(r.d, AXIS);
+    double t = (k - comp(r.o, AXIS)) * comp(inv, AXIS);
     if (t < t_min || t > t_max) return false;
     double a = comp(r.o, IA) + t * comp(r.d, IA);
     double b = comp(r.o, IB) + t * comp(r.d, IB);
@@ -191,83 +227,97 @@ __device__ __forceinline__ bool sphere_hit(D3 c, double radius, const RayD& r, d
     double disc = half_b * half_b - a * cc;
     if (disc < 0.0) return false;
     double sq = sqrt(disc);
-    double root = (-half_b - sq) / a;
+    double inv_a = rcp_fast(a);
+    double root = (-half_b - sq) * inv_a;
     if (root < t_min || t_max < root) {
-        root = (-half_b + sq) / a;
+        root = (-half_b + sq) * inv_a;
         if (root < t_min || t_max < root) return false;
     }
     t_out = root;
     return true;
 }
 // sphere.rs:139-142
-__device__ __forceinline__ D3 moving_center(const double* p, double time) {
+template <class PP>
+__device__ __forceinline__ D3 moving_center(PP p, double time) {
     double f = (time - p[7]) / (p[8] - p[7]);
     return D3{p[1], p[2], p[3]} + f * (D3{p[4], p[5], p[6]} - D3{p[1], p[2], p[3]});
 }
 // render_box.rs:117-129: faces in order xy+, xy-, xz+, xz-, yz+, yz-; strictly smaller t replaces.
-__device__ __forceinline__ bool box_hit(const double* p, const RayD& r, double t_min, double t_max, double& t_out,
+template <class PP>
+__device__ __forceinline__ bool box_hit(PP p, const RayD& r, D3 inv, double t_min, double t_max, double& t_out,
                                         int& face) {
     bool any = false;
     double best = 0.0, t;
     int f = 0;
-    if (rect_hit<2>(p[0], p[3], p[1], p[4], p[5], r, t_min, t_max, t)) { any = true, best = t, f = 0; }
-    if (rect_hit<2>(p[0], p[3], p[1], p[4], p[2], r, t_min, t_max, t) && (!any || t < best)) { any = true, best = t, f = 1; }
-    if (rect_hit<1>(p[0], p[3], p[2], p[5], p[4], r, t_min, t_max, t) && (!any || t < best)) { any = true, best = t, f = 2; }
-    if (rect_hit<1>(p[0], p[3], p[2], p[5], p[1], r, t_min, t_max, t) && (!any || t < best)) { any = true, best = t, f = 3; }
-    if (rect_hit<0>(p[1], p[4], p[2], p[5], p[3], r, t_min, t_max, t) && (!any || t < best)) { any = true, best = t, f = 4; }
-    if (rect_hit<0>(p[1], p[4], p[2], p[5], p[0], r, t_min, t_max, t) && (!any || t < best)) { any = true, best = t, f = 5; }
+    if (rect_hit<2>(p[0], p[3], p[1], p[4], p[5], r, inv, t_min, t_max, t)) { any = true, best = t, f = 0; }
+    if (rect_hit<2>(p[0], p[3], p[1], p[4], p[2], r, inv, t_min, t_max, t) && (!any || t < best)) { any = true, best = t, f = 1; }
+    if (rect_hit<1>(p[0], p[3], p[2], p[5], p[4], r, inv, t_min, t_max, t) && (!any || t < best)) { any = true, best = t, f = 2; }
+    if (rect_hit<1>(p[0], p[3], p[2], p[5], p[1], r, inv, t_min, t_max, t) && (!any || t < best)) { any = true, best = t, f = 3; }
+    if (rect_hit<0>(p[1], p[4], p[2], p[5], p[3], r, inv, t_min, t_max, t) && (!any || t < best)) { any = true, best = t, f = 4; }
+    if (rect_hit<0>(p[1], p[4], p[2], p[5], p[0], r, inv, t_min, t_max, t) && (!any || t < best)) { any = true, best = t, f = 5; }
     t_out = best;
     face = f;
     return any;
 }
 
 // Deterministic shapes (everything a ConstantMedium may wrap). `sub` = box face.
-__device__ __forceinline__ bool solid_hit(const DShape& sh, const RayD& r, double t_min, double t_max, double& t,
+template <class SP>
+__device__ __forceinline__ bool solid_hit(SP sh, const RayD& r, D3 inv, double t_min, double t_max, double& t,
                                           int& sub) {
-    const double* p = sh.p;
+    auto p = sh->p;
     sub = 0;
-    switch (sh.kind) {
+    switch (sh->kind) {
         case MRT_SHAPE_SPHERE: return sphere_hit(D3{p[1], p[2], p[3]}, p[0], r, t_min, t_max, t);
         case MRT_SHAPE_MOVING_SPHERE: return sphere_hit(moving_center(p, r.time), p[0], r, t_min, t_max, t);
-        case MRT_SHAPE_XY_RECT: return rect_hit<2>(p[0], p[1], p[2], p[3], p[4], r, t_min, t_max, t);
-        case MRT_SHAPE_XZ_RECT: return rect_hit<1>(p[0], p[1], p[2], p[3], p[4], r, t_min, t_max, t);
-        case MRT_SHAPE_YZ_RECT: return rect_hit<0>(p[0], p[1], p[2], p[3], p[4], r, t_min, t_max, t);
-        case MRT_SHAPE_RENDER_BOX: return box_hit(p, r, t_min, t_max, t, sub);
+        case MRT_SHAPE_XY_RECT: return rect_hit<2>(p[0], p[1], p[2], p[3], p[4], r, inv, t_min, t_max, t);
+        case MRT_SHAPE_XZ_RECT: return rect_hit<1>(p[0], p[1], p[2], p[3], p[4], r, inv, t_min, t_max, t);
+        case MRT_SHAPE_YZ_RECT: return rect_hit<0>(p[0], p[1], p[2], p[3], p[4], r, inv, t_min, t_max, t);
+        case MRT_SHAPE_RENDER_BOX: return box_hit(p, r, inv, t_min, t_max, t, sub);
         default: return false;
     }
 }
 
 // constant_medium.rs:35-93. One uniform draw at dimension `dim`.
-__device__ __forceinline__ bool medium_hit(const SceneView& sv, const DShape& sh, const RayD& r, double t_min,
-                                           double t_max, const Rng& g, uint32_t dim, double& t_out) {
-    const DShape& bnd = sv.shapes[sh.boundary];
+template <class SP>
+__device__ __forceinline__ bool medium_hit(SP shapes, SP sh, const RayD& r, D3 inv, double t_min, double t_max,
+                                           const Rng& g, uint32_t dim, double& t_out) {
+    SP bnd = shapes + sh->boundary;
     double t1, t2;
     int s;
-    if (!solid_hit(bnd, r, -10000000000.0, 10000000000.0, t1, s)) return false;
-    if (!solid_hit(bnd, r, t1 + 0.0001, 10000000000.0, t2, s)) return false;
+    if (!solid_hit(bnd, r, inv, -10000000000.0, 10000000000.0, t1, s)) return false;
+    if (!solid_hit(bnd, r, inv, t1 + 0.0001, 10000000000.0, t2, s)) return false;
     if (t1 < t_min) t1 = t_min;
     if (t2 > t_max) t2 = t_max;
     if (t1 >= t2) return false;
     if (t1 < 0.0) t1 = 0.0;
-    double ray_length = sqrt(r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z);
+    double len2 = r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z;
+    double ray_length = sqrt(len2);
     double distance_inside = (t2 - t1) * ray_length;
-    double neg_inv_density = -1.0 / sh.p[0];
+    double neg_inv_density = -1.0 / sh->p[0];
     double hit_distance = neg_inv_density * log(rand_scalar(g, 0.0, 1.0, dim));
     if (hit_distance > distance_inside) return false;
-    t_out = t1 + hit_distance / ray_length;
+    t_out = t1 + hit_distance * rcp_fast(ray_length);
     return true;
 }
 
 // Object::hit (hittable.rs:204-237) without the material: returns t and the sub-shape id.
-__device__ __forceinline__ bool object_hit(const SceneView& sv, const DObject& ob, const RayD& ray, double t_min,
+// `inv_world` = 1/direction of the world ray; objects with the identity transform use the world
+// ray as it is (the reference's M*(o+d) - M*o differs from d only by rounding).
+template <class OP, class SP>
+__device__ __forceinline__ bool object_hit(OP ob, SP shapes, const RayD& ray, D3 inv_world, double t_min,
                                            double t_max, const Rng& g, uint32_t medium_dim, double& t, int& sub) {
-    RayD sr = xform_ray(ob.to_object, ob.identity != 0, ray);
-    const DShape& sh = sv.shapes[ob.shape];
-    if (sh.kind == MRT_SHAPE_CONSTANT_MEDIUM) {
-        sub = 0;
-        return medium_hit(sv, sh, sr, t_min, t_max, g, medium_dim, t);
+    RayD sr = ray;
+    D3 inv = inv_world;
+    if (!ob->identity) {
+        sr = xform_ray(&ob->to_object, false, ray);
+        inv = {rcp_fast(sr.d.x), rcp_fast(sr.d.y), rcp_fast(sr.d.z)};
     }
-    return solid_hit(sh, sr, t_min, t_max, t, sub);
+    SP sh = shapes + ob->shape;
+    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) {
+        sub = 0;
+        return medium_hit(shapes, sh, sr, inv, t_min, t_max, g, medium_dim, t);
+    }
+    return solid_hit(sh, sr, inv, t_min, t_max, t, sub);
 }
 
 // Aabb::hit (bvh.rs:18-33): every axis is tested on its own against the ORIGINAL [t_min, t_max].
@@ -295,16 +345,17 @@ __device__ __forceinline__ bool aabb_hit(D3 mn, D3 mx, const RayD& r, D3 inv_d, 
 
 // Leaf box of a MovingSphere-based object for the time window (t0, t1) the reference passes
 // (bvh.rs:142-145,180; sphere.rs:175-186; hittable.rs:239-282).
-__device__ void dynamic_leaf_box(const SceneView& sv, const DObject& ob, double t0, double t1, D3& mn, D3& mx) {
-    const DShape* sh = &sv.shapes[ob.shape];
-    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = &sv.shapes[sh->boundary];
-    const double* p = sh->p;
+template <class OP, class SP>
+__device__ void dynamic_leaf_box(OP ob, SP shapes, double t0, double t1, D3& mn, D3& mx) {
+    SP sh = shapes + ob->shape;
+    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = shapes + sh->boundary;
+    auto p = sh->p;
     D3 c0 = moving_center(p, t0), c1 = moving_center(p, t1);
     D3 r{p[0], p[0], p[0]};
     D3 lo0 = c0 - r, hi0 = c0 + r, lo1 = c1 - r, hi1 = c1 + r;
     D3 smn{lo0.x < lo1.x ? lo0.x : lo1.x, lo0.y < lo1.y ? lo0.y : lo1.y, lo0.z < lo1.z ? lo0.z : lo1.z};
     D3 smx{hi0.x > hi1.x ? hi0.x : hi1.x, hi0.y > hi1.y ? hi0.y : hi1.y, hi0.z > hi1.z ? hi0.z : hi1.z};
-    D3 a = apply(ob.to_world, smn), b = apply(ob.to_world, smx);
+    D3 a = apply(&ob->to_world, smn), b = apply(&ob->to_world, smx);
     mn = {a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y, a.z < b.z ? a.z : b.z};
     mx = {a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y, a.z > b.z ? a.z : b.z};
 }
@@ -318,12 +369,14 @@ struct HitD {
 // World::nearest_hit (world.rs:112-114) -> BvhTreeNode::hit (bvh.rs:135-167), stackless over the
 // pre-order node arrays. Visiting left before right with t_max = left.t and preferring the
 // right result on ties is the same as keeping one running closest t and accepting t <= closest.
-__device__ bool nearest_hit(const SceneView& sv, const RayD& ray, const Rng& g, HitD& out) {
+//
+// Per-lane variant: every lane walks its own node sequence (large trees, incoherent rays).
+__device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng& g, HitD& out) {
     const double t_min = (double)0.001f;
     double closest = (double)FLT_MAX;
     int best_obj = -1, best_sub = 0;
     uint32_t medium_ordinal = 0;
-    D3 inv_d{1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z};
+    D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
     int i = 0;
     const int n = sv.n_nodes;
     while (i < n) {
@@ -331,26 +384,93 @@ __device__ bool nearest_hit(const SceneView& sv, const RayD& ray, const Rng& g, 
         const int flags = sv.node_flags[i];
         D3 mn{sv.bmin_x[i], sv.bmin_y[i], sv.bmin_z[i]};
         D3 mx{sv.bmax_x[i], sv.bmax_y[i], sv.bmax_z[i]};
-        if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(sv, sv.objects[obj], t_min, closest, mn, mx);
+        if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(sv.objects + obj, sv.shapes, t_min, closest, mn, mx);
         if (!aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
             i = sv.node_skip[i];
             continue;
         }
         if (obj >= 0) {
-            const DObject& ob = sv.objects[obj];
+            const DObject* ob = sv.objects + obj;
+            const bool is_medium = sv.shapes[ob->shape].kind == MRT_SHAPE_CONSTANT_MEDIUM;
             double t;
             int sub;
-            if (object_hit(sv, ob, ray, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub)) {
+            if (object_hit(ob, sv.shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub)) {
                 closest = t, best_obj = obj, best_sub = sub;
             }
-            if (sv.shapes[ob.shape].kind == MRT_SHAPE_CONSTANT_MEDIUM) medium_ordinal++;
+            if (is_medium) medium_ordinal++;
             if (flags & NODE_TWICE) {
                 // second leaf of a span-1 node: box re-tested against the updated bound, new draw
                 if (aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
-                    if (object_hit(sv, ob, ray, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub)) {
+                    if (object_hit(ob, sv.shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub)) {
                         closest = t, best_obj = obj, best_sub = sub;
                     }
                     medium_ordinal++;
+                }
+            }
+        }
+        i = i + 1;
+    }
+    out.t = closest;
+    out.obj = best_obj;
+    out.sub = best_sub;
+    return best_obj >= 0;
+}
+
+// Wave-synchronous variant for small trees: the whole wave visits the nodes in pre-order with
+// ONE node index, so node, object and shape records are read with scalar loads (SGPR operands,
+// no per-lane scene loads) and the shape-kind switch is a scalar branch. A lane that fails a
+// box test sits out until the walk leaves that subtree (`resume`); a subtree no lane wants is
+// skipped for the whole wave by a ballot. Must be called by every lane of the wave; lanes with
+// live == false only follow along.
+__device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng& g, bool live, HitD& out) {
+    const double t_min = (double)0.001f;
+    double closest = (double)FLT_MAX;
+    int best_obj = -1, best_sub = 0;
+    uint32_t medium_ordinal = 0;
+    D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
+    const int n = sv.n_nodes;
+    auto node_object = as_const(sv.node_object);
+    auto node_skip = as_const(sv.node_skip);
+    auto node_flags = as_const(sv.node_flags);
+    auto bmin_x = as_const(sv.bmin_x), bmin_y = as_const(sv.bmin_y), bmin_z = as_const(sv.bmin_z);
+    auto bmax_x = as_const(sv.bmax_x), bmax_y = as_const(sv.bmax_y), bmax_z = as_const(sv.bmax_z);
+    auto objects = as_const(sv.objects);
+    auto shapes = as_const(sv.shapes);
+    int resume = live ? 0 : n;
+    int i = 0;
+    while (i < n) {
+        const int obj = node_object[i];
+        const int flags = node_flags[i];
+        const int skip = node_skip[i];
+        D3 mn{bmin_x[i], bmin_y[i], bmin_z[i]};
+        D3 mx{bmax_x[i], bmax_y[i], bmax_z[i]};
+        bool pass = false;
+        if (i >= resume) {
+            if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(objects + obj, shapes, t_min, closest, mn, mx);
+            pass = aabb_hit(mn, mx, ray, inv_d, t_min, closest);
+            if (!pass) resume = skip;
+        }
+        if (!__any(pass)) {
+            i = skip;
+            continue;
+        }
+        if (obj >= 0) {
+            auto ob = objects + obj;
+            const bool is_medium = shapes[ob->shape].kind == MRT_SHAPE_CONSTANT_MEDIUM;
+            if (pass) {
+                double t;
+                int sub;
+                if (object_hit(ob, shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub)) {
+                    closest = t, best_obj = obj, best_sub = sub;
+                }
+                if (is_medium) medium_ordinal++;
+                if (flags & NODE_TWICE) {
+                    if (aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
+                        if (object_hit(ob, shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub)) {
+                            closest = t, best_obj = obj, best_sub = sub;
+                        }
+                        medium_ordinal++;
+                    }
                 }
             }
         }
@@ -367,9 +487,11 @@ struct Surface {
     D3 pos_obj;   // hit.position as the shape computed it (object space)
     D3 n_obj;     // geometric normal in object space (never flipped, hittable.rs:385-391)
     D3 dir_obj;   // object-space ray direction
-    double u, v;
+    D3 org_obj;   // object-space ray origin
+    double t;
     double time;  // object-space ray time (= world ray time)
     int material;
+    int sub;
     bool front_face;  // as the material sees it (object space; `true` for media, constant_medium.rs:66-72)
 };
 __device__ __forceinline__ void sphere_uv(D3 p, double& u, double& v) {  // sphere.rs:111-115
@@ -379,67 +501,75 @@ __device__ __forceinline__ void sphere_uv(D3 p, double& u, double& v) {  // sphe
     v = theta / M_PI;
 }
 template <int AXIS>
-__device__ __forceinline__ void rect_surface(double a0, double a1, double b0, double b1, double flip, const RayD& sr,
-                                             double t, Surface& s) {
+__device__ __forceinline__ void rect_uv(double a0, double a1, double b0, double b1, const Surface& s, double& u,
+                                        double& v) {
     constexpr int IA = AXIS == 0 ? 1 : 0;
     constexpr int IB = AXIS == 2 ? 1 : 2;
-    double a = comp(sr.o, IA) + t * comp(sr.d, IA);
-    double b = comp(sr.o, IB) + t * comp(sr.d, IB);
-    s.u = (a - a0) / (a1 - a0);
-    s.v = (b - b0) / (b1 - b0);
-    s.n_obj = {AXIS == 0 ? flip : 0.0, AXIS == 1 ? flip : 0.0, AXIS == 2 ? flip : 0.0};
+    double a = comp(s.org_obj, IA) + s.t * comp(s.dir_obj, IA);
+    double b = comp(s.org_obj, IB) + s.t * comp(s.dir_obj, IB);
+    u = (a - a0) / (a1 - a0);
+    v = (b - b0) / (b1 - b0);
 }
-__device__ void surface_at(const SceneView& sv, const DObject& ob, const RayD& ray, double t, int sub, Surface& s) {
-    RayD sr = xform_ray(ob.to_object, ob.identity != 0, ray);
-    const DShape& sh = sv.shapes[ob.shape];
-    const double* p = sh.p;
+// Texture coordinates of the hit; evaluated only for textures that read them.
+template <class SP>
+__device__ void surface_uv(SP sh, const Surface& s, double& u, double& v) {
+    auto p = sh->p;
+    u = 0.0, v = 0.0;
+    switch (sh->kind) {
+        case MRT_SHAPE_SPHERE:
+        case MRT_SHAPE_MOVING_SPHERE: sphere_uv(s.n_obj, u, v); break;
+        case MRT_SHAPE_XY_RECT: rect_uv<2>(p[0], p[1], p[2], p[3], s, u, v); break;
+        case MRT_SHAPE_XZ_RECT: rect_uv<1>(p[0], p[1], p[2], p[3], s, u, v); break;
+        case MRT_SHAPE_YZ_RECT: rect_uv<0>(p[0], p[1], p[2], p[3], s, u, v); break;
+        case MRT_SHAPE_RENDER_BOX:
+            if (s.sub < 2) rect_uv<2>(p[0], p[3], p[1], p[4], s, u, v);
+            else if (s.sub < 4) rect_uv<1>(p[0], p[3], p[2], p[5], s, u, v);
+            else rect_uv<0>(p[1], p[4], p[2], p[5], s, u, v);
+            break;
+        default: break;  // ConstantMedium: uv (0,0)
+    }
+}
+template <class OP, class SP>
+__device__ void surface_at(OP ob, SP shapes, const RayD& ray, double t, int sub, Surface& s) {
+    RayD sr = ob->identity ? ray : xform_ray(&ob->to_object, false, ray);
+    SP sh = shapes + ob->shape;
+    auto p = sh->p;
     s.pos_obj = ray_at(sr, t);
     s.dir_obj = sr.d;
+    s.org_obj = sr.o;
+    s.t = t;
     s.time = sr.time;
-    s.material = sh.material;
-    s.u = 0.0, s.v = 0.0;
-    switch (sh.kind) {
-        case MRT_SHAPE_SPHERE: {
-            D3 n = (s.pos_obj - D3{p[1], p[2], p[3]}) / p[0];
-            s.n_obj = n;
-            sphere_uv(n, s.u, s.v);
+    s.material = sh->material;
+    s.sub = sub;
+    switch (sh->kind) {
+        case MRT_SHAPE_SPHERE: s.n_obj = (s.pos_obj - D3{p[1], p[2], p[3]}) * rcp_fast(p[0]); break;
+        case MRT_SHAPE_MOVING_SPHERE: s.n_obj = (s.pos_obj - moving_center(p, sr.time)) * rcp_fast(p[0]); break;
+        case MRT_SHAPE_XY_RECT: s.n_obj = {0.0, 0.0, p[5]}; break;
+        case MRT_SHAPE_XZ_RECT: s.n_obj = {0.0, p[5], 0.0}; break;
+        case MRT_SHAPE_YZ_RECT: s.n_obj = {p[5], 0.0, 0.0}; break;
+        case MRT_SHAPE_RENDER_BOX: {  // render_box.rs:21-93: "+" faces unflipped, "-" faces flipped
+            double flip = (sub & 1) ? -1.0 : 1.0;
+            s.n_obj = {sub >= 4 ? flip : 0.0, (sub == 2 || sub == 3) ? flip : 0.0, sub < 2 ? flip : 0.0};
             break;
         }
-        case MRT_SHAPE_MOVING_SPHERE: {
-            D3 n = (s.pos_obj - moving_center(p, sr.time)) / p[0];
-            s.n_obj = n;
-            sphere_uv(n, s.u, s.v);
-            break;
-        }
-        case MRT_SHAPE_XY_RECT: rect_surface<2>(p[0], p[1], p[2], p[3], p[5], sr, t, s); break;
-        case MRT_SHAPE_XZ_RECT: rect_surface<1>(p[0], p[1], p[2], p[3], p[5], sr, t, s); break;
-        case MRT_SHAPE_YZ_RECT: rect_surface<0>(p[0], p[1], p[2], p[3], p[5], sr, t, s); break;
-        case MRT_SHAPE_RENDER_BOX:  // render_box.rs:21-93: "+" faces unflipped, "-" faces flipped
-            switch (sub) {
-                case 0: rect_surface<2>(p[0], p[3], p[1], p[4], 1.0, sr, t, s); break;
-                case 1: rect_surface<2>(p[0], p[3], p[1], p[4], -1.0, sr, t, s); break;
-                case 2: rect_surface<1>(p[0], p[3], p[2], p[5], 1.0, sr, t, s); break;
-                case 3: rect_surface<1>(p[0], p[3], p[2], p[5], -1.0, sr, t, s); break;
-                case 4: rect_surface<0>(p[1], p[4], p[2], p[5], 1.0, sr, t, s); break;
-                default: rect_surface<0>(p[1], p[4], p[2], p[5], -1.0, sr, t, s); break;
-            }
-            break;
-        default:  // ConstantMedium: normal (1,0,0), uv (0,0), front_face true for the phase function
+        default:  // ConstantMedium: normal (1,0,0), front_face true for the phase function
             s.n_obj = {1.0, 0.0, 0.0};
             break;
     }
-    s.front_face = sh.kind == MRT_SHAPE_CONSTANT_MEDIUM ? true : (dot(sr.d, s.n_obj) <= 0.0);
+    s.front_face = sh->kind == MRT_SHAPE_CONSTANT_MEDIUM ? true : (dot(sr.d, s.n_obj) <= 0.0);
 }
-__device__ __forceinline__ D3 normal_to_world(const DObject& ob, D3 n) {  // hittable.rs:215-220
-    if (ob.identity) return n;
+template <class OP>
+__device__ __forceinline__ D3 normal_to_world(OP ob, D3 n) {  // hittable.rs:215-220
+    if (ob->identity) return n;
     // cgmath Matrix3 * Vector3 = col0*x + col1*y + col2*z; normal_m holds rows
-    return {(ob.normal_m[0][0] * n.x + ob.normal_m[0][1] * n.y) + ob.normal_m[0][2] * n.z,
-            (ob.normal_m[1][0] * n.x + ob.normal_m[1][1] * n.y) + ob.normal_m[1][2] * n.z,
-            (ob.normal_m[2][0] * n.x + ob.normal_m[2][1] * n.y) + ob.normal_m[2][2] * n.z};
+    return {(ob->normal_m[0][0] * n.x + ob->normal_m[0][1] * n.y) + ob->normal_m[0][2] * n.z,
+            (ob->normal_m[1][0] * n.x + ob->normal_m[1][1] * n.y) + ob->normal_m[1][2] * n.z,
+            (ob->normal_m[2][0] * n.x + ob->normal_m[2][1] * n.y) + ob->normal_m[2][2] * n.z};
 }
-__device__ __forceinline__ D3 point_to_world(const DObject& ob, D3 p) {
-    if (ob.identity) return p;
-    return apply(ob.to_world, p);
+template <class OP>
+__device__ __forceinline__ D3 point_to_world(OP ob, D3 p) {
+    if (ob->identity) return p;
+    return apply(&ob->to_world, p);
 }
 
 // ============================================================== textures (texture.rs)
@@ -448,8 +578,11 @@ __device__ __forceinline__ uint32_t f64_as_index(double v, uint32_t hi) {  // Ru
     if (v >= (double)hi) return hi;
     return (uint32_t)v;
 }
-__device__ F3 texture_color(const SceneView& sv, int tex, double u, double v, D3 pos) {
+__device__ F3 texture_color(const SceneView& sv, int tex, const DShape* sh, const Surface& sf) {
     F3 acc{1.f, 1.f, 1.f};
+    const D3 pos = sf.pos_obj;
+    double u = 0.0, v = 0.0;
+    bool have_uv = false;
     int stack[8];
     int sp = 0;
     int cur = tex;
@@ -460,6 +593,7 @@ __device__ F3 texture_color(const SceneView& sv, int tex, double u, double v, D3
         switch (t.kind) {
             case MRT_TEX_SOLID: c = {t.color[0], t.color[1], t.color[2]}; break;
             case MRT_TEX_IMAGE: {  // parallel_image.rs:66-71
+                if (!have_uv) surface_uv(sh, sf, u, v), have_uv = true;
                 const DImage& im = sv.images[t.image];
                 uint32_t x = f64_as_index(u * ((double)im.width - 1.0), (uint32_t)im.width - 1);
                 double vv = 1.0 - v;
@@ -469,6 +603,7 @@ __device__ F3 texture_color(const SceneView& sv, int tex, double u, double v, D3
                 break;
             }
             case MRT_TEX_DEBUG_V:  // texture.rs:231-238
+                if (!have_uv) surface_uv(sh, sf, u, v), have_uv = true;
                 c = (v != v) ? F3{0.f, 0.f, 0.f} : F3{(float)v, (float)v, (float)v};
                 break;
             case MRT_TEX_MULTIPLY:  // texture.rs:29-31
@@ -506,11 +641,12 @@ __device__ __forceinline__ double rect_prob(double a0, double a1, double b0, dou
     double cos_alpha = fabs(comp(normalize(to_light), AXIS));
     if (cos_alpha < 0.00001) return 0.0;
     double area = (a1 - a0) * (b1 - b0);
-    return dot(to_light, to_light) / (cos_alpha * area);
+    return dot(to_light, to_light) * rcp_fast(cos_alpha * area);
 }
-__device__ double shape_prob(const SceneView& sv, const DShape* sh, const RayD& r) {
-    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = &sv.shapes[sh->boundary];  // constant_medium.rs:98-100
-    const double* p = sh->p;
+template <class SP>
+__device__ double shape_prob(SP shapes, SP sh, const RayD& r) {
+    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = shapes + sh->boundary;  // constant_medium.rs:98-100
+    auto p = sh->p;
     switch (sh->kind) {
         case MRT_SHAPE_SPHERE: {
             double area = M_PI * (p[0] * p[0]);
@@ -551,10 +687,10 @@ __device__ __forceinline__ void rect_generate(double a0, double a1, double b0, d
     o.direction = end_point - origin;
     o.end_point = end_point;
 }
-__device__ void shape_generate(const SceneView& sv, const DShape* sh, D3 origin, double time, const Rng& g,
-                               AreaInfo& o) {
-    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = &sv.shapes[sh->boundary];  // constant_medium.rs:101-103
-    const double* p = sh->p;
+template <class SP>
+__device__ void shape_generate(SP shapes, SP sh, D3 origin, double time, const Rng& g, AreaInfo& o) {
+    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = shapes + sh->boundary;  // constant_medium.rs:101-103
+    auto p = sh->p;
     switch (sh->kind) {
         case MRT_SHAPE_SPHERE: {  // sphere.rs:72-87
             D3 sd = rand_unit_vec(g, MRT_DIM_LIGHT_SPHERE);
@@ -588,11 +724,11 @@ __device__ void shape_generate(const SceneView& sv, const DShape* sh, D3 origin,
     }
 }
 // Object::generate_ray_in_area, hittable.rs:289-312
-__device__ void object_generate(const SceneView& sv, const DObject& ob, D3 origin, double time, const Rng& g,
-                                AreaInfo& out) {
-    const DShape* sh = &sv.shapes[ob.shape];
-    if (ob.identity) {
-        shape_generate(sv, sh, origin, time, g, out);
+template <class OP, class SP>
+__device__ void object_generate(OP ob, SP shapes, D3 origin, double time, const Rng& g, AreaInfo& out) {
+    SP sh = shapes + ob->shape;
+    if (ob->identity) {
+        shape_generate(shapes, sh, origin, time, g, out);
         // the reference still routes every vector through the (identity) inverse
         D3 o = out.to_area.o;
         out.to_area.d = (o + out.to_area.d) - o;
@@ -601,8 +737,8 @@ __device__ void object_generate(const SceneView& sv, const DObject& ob, D3 origi
         return;
     }
     AreaInfo a;
-    shape_generate(sv, sh, apply(ob.to_object, origin), time, g, a);
-    const Affine& inv = ob.to_world;
+    shape_generate(shapes, sh, apply(&ob->to_object, origin), time, g, a);
+    auto inv = &ob->to_world;
     out.end_point = apply(inv, a.end_point);
     out.to_area = xform_ray(inv, false, a.to_area);
     D3 sc = apply(inv, D3{1.0, 0.0, 0.0}) - apply(inv, D3{0.0, 0.0, 0.0});
@@ -619,21 +755,24 @@ __device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng&
     double best_t = 0.0;
     int best = -1, best_sub = 0;
     uint32_t ordinal = 0;
+    auto lights = as_const(sv.lights);  // the loop index is wave-uniform: scalar loads
+    auto cshapes = as_const(sv.shapes);
+    D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
     for (int i = 0; i < sv.n_lights; ++i) {
-        const DObject& ob = sv.lights[i];
+        auto lob = lights + i;
         double t;
         int sub;
-        bool h = object_hit(sv, ob, ray, ray.time, DBL_MAX, g, MRT_DIM_LIGHT_QUERY_MEDIUM + ordinal, t, sub);
-        if (sv.shapes[ob.shape].kind == MRT_SHAPE_CONSTANT_MEDIUM) ordinal++;
+        bool h = object_hit(lob, cshapes, ray, inv_d, ray.time, DBL_MAX, g, MRT_DIM_LIGHT_QUERY_MEDIUM + ordinal, t, sub);
+        if (cshapes[lob->shape].kind == MRT_SHAPE_CONSTANT_MEDIUM) ordinal++;
         if (!h) continue;
         if (!any || !(best_t < t)) {  // reduce(|acc, x| if acc.t < x.t { acc } else { x })
             any = true, best_t = t, best = i, best_sub = sub;
         }
     }
     if (!any) return false;
-    const DObject& ob = sv.lights[best];
+    const DObject* ob = sv.lights + best;
     Surface s;
-    surface_at(sv, ob, ray, best_t, best_sub, s);
+    surface_at(ob, sv.shapes, ray, best_t, best_sub, s);
     D3 hit_pos = point_to_world(ob, s.pos_obj);
     D3 hit_n = normal_to_world(ob, s.n_obj);
     D3 to_light = hit_pos - ray.o;
@@ -641,8 +780,8 @@ __device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng&
     if (light_cos >= 0.000001) {
         // Object::prob applies the INVERSE transform to the ray (hittable.rs:284-287)
         RayD pr{ray.o, normalize(to_light), best_t};
-        RayD tr = xform_ray(ob.to_world, ob.identity != 0, pr);
-        value = shape_prob(sv, &sv.shapes[ob.shape], tr);
+        RayD tr = xform_ray(&ob->to_world, ob->identity != 0, pr);
+        value = shape_prob(sv.shapes, sv.shapes + ob->shape, tr);
     } else {
         value = 0.0;
     }
@@ -676,22 +815,23 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
         double r1 = rand_scalar(g, 0.0, 1.0, MRT_DIM_COS_R1);
         double r2 = rand_scalar(g, 0.0, 1.0, MRT_DIM_COS_R2);
         double z = sqrt(1.0 - r2);
-        double phi = 2.0 * M_PI * r1;
         double sr2 = sqrt(r2);
-        double x = cos(phi) * sr2, y = sin(phi) * sr2;
+        double sphi, cphi;
+        sincospi(2.0 * r1, &sphi, &cphi);  // phi = 2 pi r1
+        double x = cphi * sr2, y = sphi * sr2;
         dir = normalize(x * uvw.u + y * uvw.v + z * uvw.w);
         double c = dot(dir, uvw.w);
-        own = c <= 0.0 ? 0.0 : c / M_PI;
+        own = c <= 0.0 ? 0.0 : c * INV_PI;
     } else if (r == 1) {  // LightPdf::generate, pdf.rs:104-130
         if (sv.n_lights == 0) return false;
         uint32_t idx = rand_u32(g, 0, (uint32_t)sv.n_lights, MRT_DIM_LIGHT_INDEX);
         AreaInfo ai;
-        object_generate(sv, sv.lights[idx], hit_point, incoming_time, g, ai);
+        object_generate(sv.lights + idx, sv.shapes, hit_point, incoming_time, g, ai);
         D3 nd = normalize(ai.to_area.d);
         double light_cos = fabs(dot(nd, ai.normal));
         double dist_squared = dot(ai.direction, ai.direction);
         if (!(light_cos >= 0.000001)) return false;
-        own = dist_squared / (light_cos * ai.area);
+        own = dist_squared * rcp_fast(light_cos * ai.area);
         dir = nd;
     } else {  // SkyPdf::generate, pdf.rs:154-193
         if (!sv.sun.has_sun) {
@@ -717,7 +857,7 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
     }
     if (r != 0) {  // sin_pdf.value, pdf.rs:32-39 (direction NOT normalised here)
         double c = dot(dir, uvw.w);
-        sum += c <= 0.0 ? 0.0 : c / M_PI;
+        sum += c <= 0.0 ? 0.0 : c * INV_PI;
         total++;
     }
     if (r != 2) {  // sky_pdf.value, pdf.rs:135-148
@@ -786,28 +926,38 @@ __device__ __forceinline__ D3 reflect(D3 v, D3 n) { return v - 2.0 * dot(v, n) *
 // "throughput *= attenuation [/ value]"; the terminal value is emitted light, background or black.
 // Returns true when the path continues with `ray` / `thr` updated; otherwise `radiance` holds the
 // path's contribution (already multiplied by the throughput).
-__device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, F3& radiance,
+// `live` marks the lanes that carry a path; with WAVE the traversal is wave-synchronous and every
+// lane of the wave must call this function.
+template <bool WAVE>
+__device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, bool live, F3& radiance,
                              uint32_t& rays, uint32_t& light_queries) {
     radiance = {0.f, 0.f, 0.f};
-    HitD h;
+    HitD h{0.0, -1, 0};
+    bool hit;
+    if (WAVE) {
+        hit = nearest_hit_wave(sv, ray, g, live, h);
+    } else {
+        hit = live && nearest_hit_lane(sv, ray, g, h);
+    }
+    if (!live) return false;
     rays++;
-    if (!nearest_hit(sv, ray, g, h)) {
+    if (!hit) {
         F3 bg = background_color(sv, ray);
         radiance = thr * bg;
         return false;
     }
-    const DObject& ob = sv.objects[h.obj];
+    const DObject* ob = sv.objects + h.obj;
     Surface s;
-    surface_at(sv, ob, ray, h.t, h.sub, s);
+    surface_at(ob, sv.shapes, ray, h.t, h.sub, s);
     const DMaterial& m = sv.materials[s.material];
     // HitRecord::new (hittable.rs:414-448): emit first, else scatter, else nothing.
     switch (m.kind) {
         case MRT_MAT_DIFFUSE_LIGHT: {  // material.rs:236-248
-            if (s.front_face) radiance = thr * texture_color(sv, m.texture, s.u, s.v, s.pos_obj);
+            if (s.front_face) radiance = thr * texture_color(sv, m.texture, sv.shapes + ob->shape, s);
             return false;
         }
         case MRT_MAT_LAMBERTIAN: {  // material.rs:54-64 + ray_tracer.rs:230-268
-            F3 att = texture_color(sv, m.texture, s.u, s.v, s.pos_obj);
+            F3 att = texture_color(sv, m.texture, sv.shapes + ob->shape, s);
             D3 pos_w = point_to_world(ob, s.pos_obj);
             D3 n_w = normal_to_world(ob, s.n_obj);
             D3 dir;
@@ -815,9 +965,9 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
             if (!lambertian_generate(sv, s.n_obj, ray.time, pos_w, g, light_queries, dir, value)) return false;
             double cosine = dot(n_w, normalize(dir));  // Lambertian::scattering_pdf_fn, material.rs:30-41
             if (cosine < 0.0) return false;
-            double scattering_pdf = cosine / M_PI;
+            double scattering_pdf = cosine * INV_PI;
             if (scattering_pdf == 0.0) return false;
-            float fv = (float)(value / scattering_pdf);
+            float fv = (float)(value * rcp_fast(scattering_pdf));
             thr = {thr.r * att.r / fv, thr.g * att.g / fv, thr.b * att.b / fv};
             ray = {pos_w, dir, h.t};
             break;
@@ -825,7 +975,7 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
         case MRT_MAT_METAL: {  // material.rs:105-124; the specular ray stays in OBJECT space
             D3 reflected = reflect(normalize(s.dir_obj), s.n_obj);
             if (!(dot(reflected, s.n_obj) > 0.0)) return false;
-            F3 att = texture_color(sv, m.texture, s.u, s.v, s.pos_obj);
+            F3 att = texture_color(sv, m.texture, sv.shapes + ob->shape, s);
             thr = thr * att;
             ray = {s.pos_obj, reflected + m.fuzz * rand_unit_vec(g, MRT_DIM_METAL_FUZZ), s.time};
             break;
@@ -854,7 +1004,7 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
             break;
         }
         default: {  // MRT_MAT_ISOTROPIC, material.rs:274-285
-            F3 att = texture_color(sv, m.texture, s.u, s.v, s.pos_obj);
+            F3 att = texture_color(sv, m.texture, sv.shapes + ob->shape, s);
             thr = thr * att;
             ray = {s.pos_obj, rand_unit_vec(g, MRT_DIM_ISOTROPIC), s.time};
             break;
@@ -867,6 +1017,9 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
 
 // ============================================================== kernels
 constexpr int BLOCK = 256;
+#ifndef SEG_WAVES_PER_SIMD
+#define SEG_WAVES_PER_SIMD 2
+#endif
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -875,7 +1028,8 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // One launch = up to `steps` segments for every slot of the pool.
-__global__ void __launch_bounds__(BLOCK) k_segments(SceneView sv, Pool pool, RenderParams rp, Counters* ctr) {
+template <bool WAVE>
+__global__ void __launch_bounds__(BLOCK, SEG_WAVES_PER_SIMD) k_segments(SceneView sv, Pool pool, RenderParams rp, Counters* ctr) {
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     const bool in_range = slot < rp.n_slots;
     int32_t seg = -1;
@@ -924,10 +1078,12 @@ __global__ void __launch_bounds__(BLOCK) k_segments(SceneView sv, Pool pool, Ren
                 }
             }
         }
-        if (seg >= 0) {
-            Rng g{key, (uint32_t)seg};
-            F3 radiance;
-            bool cont = path_segment(sv, ray, thr, g, radiance, rays, light_queries);
+        const bool live = seg >= 0;
+        if (WAVE && !__any(live)) break;
+        Rng g{key, (uint32_t)(live ? seg : 0)};
+        F3 radiance;
+        bool cont = path_segment<WAVE>(sv, ray, thr, g, live, radiance, rays, light_queries);
+        if (live) {
             seg++;
             if (cont && seg >= 50) cont = false;  // depth 50 -> 0 returns BLACK (ray_tracer.rs:166-172, :451)
             if (!cont) {
@@ -1002,21 +1158,26 @@ __global__ void __launch_bounds__(BLOCK) k_camera_rays(SceneView sv, uint32_t wi
     double* o = out + 7 * (size_t)i;
     o[0] = r.o.x, o[1] = r.o.y, o[2] = r.o.z, o[3] = r.d.x, o[4] = r.d.y, o[5] = r.d.z, o[6] = r.time;
 }
+template <bool WAVE>
 __global__ void __launch_bounds__(BLOCK) k_trace_rays(SceneView sv, const double* rays, uint32_t n, uint64_t seed,
                                                       int32_t* obj_id, double* t_out, double* normal,
                                                       double* position, int32_t* front_face) {
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const double* r = rays + 7 * (size_t)i;
-    RayD ray{{r[0], r[1], r[2]}, {r[3], r[4], r[5]}, r[6]};
+    const bool live = i < n;
+    RayD ray{{0, 0, 0}, {0, 0, 1}, 0};
+    if (live) {
+        const double* r = rays + 7 * (size_t)i;
+        ray = {{r[0], r[1], r[2]}, {r[3], r[4], r[5]}, r[6]};
+    }
     Rng g{path_key(seed, (uint64_t)i, 0), 0};
-    HitD h;
-    bool hit = nearest_hit(sv, ray, g, h);
+    HitD h{0.0, -1, 0};
+    bool hit = WAVE ? nearest_hit_wave(sv, ray, g, live, h) : (live && nearest_hit_lane(sv, ray, g, h));
+    if (!live) return;
     D3 n_w{0, 0, 0}, p_w{0, 0, 0};
     if (hit) {
-        const DObject& ob = sv.objects[h.obj];
+        const DObject* ob = sv.objects + h.obj;
         Surface s;
-        surface_at(sv, ob, ray, h.t, h.sub, s);
+        surface_at(ob, sv.shapes, ray, h.t, h.sub, s);
         n_w = normal_to_world(ob, s.n_obj);
         p_w = point_to_world(ob, s.pos_obj);
     }
@@ -1091,8 +1252,17 @@ struct mrt_scene {
     int64_t opt_steps = 4;
     int64_t opt_trace_zero = 0;
     int64_t opt_compact = 1;
+    int64_t opt_traversal = 0;  // 0 auto, 1 per-lane, 2 wave-synchronous
     std::mutex mu;
 };
+
+// Trees of at most this many nodes are walked wave-synchronously.
+constexpr int WAVE_SYNC_MAX_NODES = 64;
+static bool use_wave_sync(const mrt_scene* sc) {
+    if (sc->opt_traversal == 1) return false;
+    if (sc->opt_traversal == 2) return true;
+    return (int)sc->flat.node_object.size() <= WAVE_SYNC_MAX_NODES;
+}
 
 namespace {
 
@@ -1170,6 +1340,7 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     uint32_t n_slots = (uint32_t)std::min<unsigned long long>(sc->pool_slots, (rp.n_work + BLOCK - 1) / BLOCK * BLOCK);
     SceneView view = sc->view;
     view.trace_zero_throughput = (int32_t)sc->opt_trace_zero;
+    const bool wave_sync = use_wave_sync(sc);
 
     hipEvent_t ev_begin, ev_end, ek0, ek1;
     HIP_TRY(hipEventCreate(&ev_begin));
@@ -1197,8 +1368,12 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
         HIP_TRY(hipMemsetAsync(&sc->counters->live, 0, sizeof(unsigned int) * 2, stream));
         rp.n_slots = active;
         HIP_TRY(hipEventRecord(ek0, stream));
-        hipLaunchKernelGGL(k_segments, dim3((active + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, view,
-                           sc->pool[cur], rp, sc->counters);
+        if (wave_sync)
+            hipLaunchKernelGGL(k_segments<true>, dim3((active + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, view,
+                               sc->pool[cur], rp, sc->counters);
+        else
+            hipLaunchKernelGGL(k_segments<false>, dim3((active + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, view,
+                               sc->pool[cur], rp, sc->counters);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ek1, stream));
         HIP_TRY(hipMemcpyAsync(&host, sc->counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
@@ -1329,6 +1504,9 @@ int mrt_scene_set_option(mrt_scene* scene, const char* name, int64_t value) {
         scene->opt_trace_zero = value ? 1 : 0;
     } else if (n == "compaction") {
         scene->opt_compact = value ? 1 : 0;
+    } else if (n == "traversal") {
+        if (value < 0 || value > 2) return set_error(MRT_ERR_INVALID_ARGUMENT, "traversal must be 0, 1 or 2");
+        scene->opt_traversal = value;
     } else {
         return set_error(MRT_ERR_INVALID_ARGUMENT, "unknown option: " + n);
     }
@@ -1380,8 +1558,12 @@ int mrt_trace_rays(mrt_scene* scene, const double* rays, size_t n, uint64_t seed
     if (position && (rc = tmp.alloc(sizeof(double) * 3 * n, (void**)&dp)) != MRT_OK) return rc;
     if (front_face && (rc = tmp.alloc(sizeof(int32_t) * n, (void**)&dff)) != MRT_OK) return rc;
     HIP_TRY(hipMemcpy(drays, rays, sizeof(double) * 7 * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_trace_rays, dim3(((uint32_t)n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, scene->view, drays,
-                       (uint32_t)n, seed, did, dt, dn, dp, dff);
+    if (use_wave_sync(scene))
+        hipLaunchKernelGGL(k_trace_rays<true>, dim3(((uint32_t)n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, scene->view,
+                           drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
+    else
+        hipLaunchKernelGGL(k_trace_rays<false>, dim3(((uint32_t)n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, scene->view,
+                           drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     if (obj_id) HIP_TRY(hipMemcpy(obj_id, did, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
