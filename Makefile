@@ -20,8 +20,8 @@ $(LIB): $(CSRC)/mrt_device.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_internal.h inclu
 oracle: $(ORACLE)
 
 # -march=native is deliberately NOT used: the .so is built here and run on the GPU box's host.
-$(ORACLE): oracle/cpu_ref.cpp oracle/octree_ref.h include/mrt.h
-	$(CXX) $(CXXFLAGS) -shared -pthread -o $@ oracle/cpu_ref.cpp
+$(ORACLE): oracle/cpu_ref.cpp oracle/octree_api.cpp oracle/octree_ref.h include/mrt.h
+	$(CXX) $(CXXFLAGS) -shared -pthread -o $@ oracle/cpu_ref.cpp oracle/octree_api.cpp
 
 clean:
 	rm -f $(LIB) $(ORACLE)

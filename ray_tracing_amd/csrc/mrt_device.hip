@@ -51,8 +51,7 @@ struct SceneView {
     const DImage* images;
     const float* image_pool;
     const DOctree* octrees;
-    const mrt_oct_node* oct_nodes;
-    const uint32_t* oct_children;
+    const DOctNode* oct_nodes;
     const mrt_voxel* oct_voxels;
     DCamera cam;
     mrt_background bg;
@@ -300,26 +299,6 @@ __device__ __forceinline__ bool medium_hit(SP shapes, SP sh, const RayD& r, D3 i
     return true;
 }
 
-// Object::hit (hittable.rs:204-237) without the material: returns t and the sub-shape id.
-// `inv_world` = 1/direction of the world ray; objects with the identity transform use the world
-// ray as it is (the reference's M*(o+d) - M*o differs from d only by rounding).
-template <class OP, class SP>
-__device__ __forceinline__ bool object_hit(OP ob, SP shapes, const RayD& ray, D3 inv_world, double t_min,
-                                           double t_max, const Rng& g, uint32_t medium_dim, double& t, int& sub) {
-    RayD sr = ray;
-    D3 inv = inv_world;
-    if (!ob->identity) {
-        sr = xform_ray(&ob->to_object, false, ray);
-        inv = {rcp_fast(sr.d.x), rcp_fast(sr.d.y), rcp_fast(sr.d.z)};
-    }
-    SP sh = shapes + ob->shape;
-    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) {
-        sub = 0;
-        return medium_hit(shapes, sh, sr, inv, t_min, t_max, g, medium_dim, t);
-    }
-    return solid_hit(sh, sr, inv, t_min, t_max, t, sub);
-}
-
 // Aabb::hit (bvh.rs:18-33): every axis is tested on its own against the ORIGINAL [t_min, t_max].
 __device__ __forceinline__ bool aabb_hit(D3 mn, D3 mx, const RayD& r, D3 inv_d, double t_min, double t_max) {
     {
@@ -343,6 +322,215 @@ __device__ __forceinline__ bool aabb_hit(D3 mn, D3 mx, const RayD& r, D3 inv_d, 
     return true;
 }
 
+// ============================================================== voxel octree (fast_oct_tree/)
+// Leaf / empty chunk that contains cell (x, y, z) (in range): get_chunk_size + get_chunk
+// (ray_trace.rs:23-83) in one root-to-leaf descent over the breadth-first node array.
+__device__ __forceinline__ DOctNode oct_chunk(const DOctNode* nodes, uint32_t root, int32_t x, int32_t y, int32_t z) {
+    DOctNode n = nodes[root];
+    while ((n.kind_size & 0xFF) == MRT_OCT_PARENT) {
+        uint32_t cs = (n.kind_size >> 8) - 1;
+        // Node::world_pos_to_child_index (mod.rs:217-225): child order x*4 + y*2 + z
+        uint32_t ci = ((((uint32_t)x >> cs) & 1u) << 2) | ((((uint32_t)y >> cs) & 1u) << 1) | (((uint32_t)z >> cs) & 1u);
+        n = nodes[(uint32_t)n.link + ci];
+    }
+    return n;
+}
+__device__ __forceinline__ int32_t f64_as_i32(double v) {  // Rust `as i32`: toward zero, saturating, NaN -> 0
+    if (v != v) return 0;
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return (int32_t)0x80000000;
+    return (int32_t)v;
+}
+__device__ __forceinline__ int32_t floor_size(int32_t v, uint32_t s) { return (v >> s) << s; }  // ray_trace.rs:686-688
+
+// ray_iteration (ray_trace.rs:86-560) for solid voxels: walk leaf to leaf until a solid leaf is
+// entered. `cur` starts at the ray origin. Returns false for None. normal_code: 0 -x, 1 +x, 2 -y, 3 +y, 4 -z, 5 +z.
+__device__ bool oct_ray_iteration(const DOctNode* nodes, const DOctree& oc, int32_t bx, int32_t by, int32_t bz, D3 origin,
+                                  D3 d, D3& hit_pos, int& normal_code, int& voxel) {
+    const int32_t ws = (int32_t)(1u << oc.world_log2);
+    auto in_range = [&](int32_t x, int32_t y, int32_t z) {
+        return x >= 0 && x < ws && y >= 0 && y < ws && z >= 0 && z < ws;
+    };
+    if (!in_range(bx, by, bz)) return false;  // get_chunk(..).expect("out of range")
+    DOctNode chunk = oct_chunk(nodes, oc.root, bx, by, bz);
+    uint32_t csz = chunk.kind_size >> 8;
+    bx = floor_size(bx, csz), by = floor_size(by, csz), bz = floor_size(bz, csz);
+    D3 cur = origin;
+    // a solid starting cell is ignored (ray_trace.rs:508)
+    const double sx = __builtin_signbit(d.x) ? 0.0 : 1.0, sy = __builtin_signbit(d.y) ? 0.0 : 1.0,
+                 sz = __builtin_signbit(d.z) ? 0.0 : 1.0;
+    const D3 inv{rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z)};
+    int32_t step = 1 << csz;  // get_step_size of the current block
+    for (int it = 0; it < 3000; ++it) {
+        if (!in_range(bx, by, bz)) return false;
+        double tx = ((double)bx + (double)step * sx - cur.x) * inv.x;
+        double ty = ((double)by + (double)step * sy - cur.y) * inv.y;
+        double tz = ((double)bz + (double)step * sz - cur.z) * inv.z;
+        if (tx < 0.0 || ty < 0.0 || tz < 0.0) return false;
+        DOctNode node;
+        if (tx < ty && tx < tz) {
+            cur.y += tx * d.y;
+            cur.z += tx * d.z;
+            int32_t cy = f64_as_i32(cur.y), cz = f64_as_i32(cur.z);
+            if (d.x >= 0.0) {
+                bx += step * (__builtin_signbit(d.x) ? -1 : 1);
+                cur.x += tx * d.x;
+                if (!in_range(bx, cy, cz)) return false;
+                node = oct_chunk(nodes, oc.root, bx, cy, cz);
+                uint32_t ncs = node.kind_size >> 8;
+                by = floor_size(cy, ncs), bz = floor_size(cz, ncs);
+                normal_code = 0;
+            } else {
+                if (!in_range(bx - 1, by, bz)) return false;
+                cur.x += tx * d.x;
+                if (!in_range(bx - 1, cy, cz)) return false;  // get_chunk_size panics out of range
+                node = oct_chunk(nodes, oc.root, bx - 1, cy, cz);
+                uint32_t ncs = node.kind_size >> 8;
+                by = floor_size(cy, ncs), bz = floor_size(cz, ncs);
+                bx -= 1 << ncs;
+                normal_code = 1;
+            }
+        } else if (ty < tx && ty < tz) {
+            cur.x += ty * d.x;
+            cur.z += ty * d.z;
+            int32_t cx = f64_as_i32(cur.x), cz = f64_as_i32(cur.z);
+            if (d.y >= 0.0) {
+                by += step * (__builtin_signbit(d.y) ? -1 : 1);
+                cur.y += ty * d.y;
+                if (!in_range(cx, by, cz)) return false;
+                node = oct_chunk(nodes, oc.root, cx, by, cz);
+                uint32_t ncs = node.kind_size >> 8;
+                bx = floor_size(cx, ncs), bz = floor_size(cz, ncs);
+                normal_code = 2;
+            } else {
+                if (!in_range(bx, by - 1, bz)) return false;
+                cur.y += ty * d.y;
+                if (!in_range(cx, by - 1, cz)) return false;
+                node = oct_chunk(nodes, oc.root, cx, by - 1, cz);
+                uint32_t ncs = node.kind_size >> 8;
+                bx = floor_size(cx, ncs), bz = floor_size(cz, ncs);
+                by -= 1 << ncs;
+                normal_code = 3;
+            }
+        } else {  // ties fall into the z branch (ray_trace.rs:398)
+            cur.y += tz * d.y;
+            cur.x += tz * d.x;
+            int32_t cx = f64_as_i32(cur.x), cy = f64_as_i32(cur.y);
+            if (d.z >= 0.0) {
+                bz += step * (__builtin_signbit(d.z) ? -1 : 1);
+                cur.z += tz * d.z;
+                if (!in_range(cx, cy, bz)) return false;
+                node = oct_chunk(nodes, oc.root, cx, cy, bz);
+                uint32_t ncs = node.kind_size >> 8;
+                by = floor_size(cy, ncs), bx = floor_size(cx, ncs);
+                normal_code = 4;
+            } else {
+                if (!in_range(bx, by, bz - 1)) return false;
+                cur.z += tz * d.z;
+                if (!in_range(cx, cy, bz - 1)) return false;
+                node = oct_chunk(nodes, oc.root, cx, cy, bz - 1);
+                uint32_t ncs = node.kind_size >> 8;
+                bx = floor_size(cx, ncs), by = floor_size(cy, ncs);
+                bz -= 1 << ncs;
+                normal_code = 5;
+            }
+        }
+        if ((node.kind_size & 0xFF) == MRT_OCT_LEAF) {  // handle_hit: StopIterationSolid
+            hit_pos = cur;
+            voxel = node.link;
+            return true;
+        }
+        step = 1 << (node.kind_size >> 8);
+    }
+    return false;  // "Max number of iterations reached"
+}
+
+// FastOctTree::trace_ray (ray_trace.rs:561-683); `d` is the normalised direction.
+__device__ bool oct_trace_ray(const DOctNode* nodes, const DOctree& oc, D3 o, D3 d, D3& hit_pos, int& normal_code,
+                              int& voxel) {
+    const double ws = (double)(1u << oc.world_log2);
+    if (o.x >= 0.0 && o.x <= ws && o.y >= 0.0 && o.y <= ws && o.z >= 0.0 && o.z <= ws) {
+        return oct_ray_iteration(nodes, oc, f64_as_i32(o.x), f64_as_i32(o.y), f64_as_i32(o.z), o, d, hit_pos,
+                                 normal_code, voxel);
+    }
+    double v0 = (0.0 - o.x) / d.x, v1 = (ws - o.x) / d.x;
+    double v2 = (0.0 - o.y) / d.y, v3 = (ws - o.y) / d.y;
+    double v4 = (0.0 - o.z) / d.z, v5 = (ws - o.z) / d.z;
+    // entry = the largest of the per-axis near planes, exit = the smallest of the far planes
+    int min_x = v0 < v1 ? 0 : 1, min_y = v2 < v3 ? 2 : 3, min_z = v4 < v5 ? 4 : 5;
+    double nx = v0 < v1 ? v0 : v1, fx = v0 < v1 ? v1 : v0;
+    double ny = v2 < v3 ? v2 : v3, fy = v2 < v3 ? v3 : v2;
+    double nz = v4 < v5 ? v4 : v5, fz = v4 < v5 ? v5 : v4;
+    int min_index;
+    double vmin;
+    if (nx > ny && nx > nz) min_index = min_x, vmin = nx;
+    else if (ny > nx && ny > nz) min_index = min_y, vmin = ny;
+    else min_index = min_z, vmin = nz;
+    double vmax;
+    if (fx < fy && fx < fz) vmax = fx;
+    else if (fy < fx && fy < fz) vmax = fy;
+    else vmax = fz;
+    if (!(vmax >= vmin && vmin >= 0.0)) return false;
+    D3 position = o + vmin * d;
+    // BLOCK_OFFSETS: -1 on the axis of a "far side" entry plane (indices 1, 3, 5)
+    int32_t bx = f64_as_i32(position.x) + (min_index == 1 ? -1 : 0);
+    int32_t by = f64_as_i32(position.y) + (min_index == 3 ? -1 : 0);
+    int32_t bz = f64_as_i32(position.z) + (min_index == 5 ? -1 : 0);
+    const int32_t wsi = (int32_t)(1u << oc.world_log2);
+    // self.get(block as u32): a negative coordinate wraps and is out of range -> None
+    if (bx >= 0 && bx < wsi && by >= 0 && by < wsi && bz >= 0 && bz < wsi) {
+        DOctNode n = oct_chunk(nodes, oc.root, bx, by, bz);
+        if ((n.kind_size & 0xFF) == MRT_OCT_LEAF) {
+            hit_pos = position;
+            normal_code = min_index;  // NORMALS[min_index]: 0 -x, 1 +x, 2 -y, 3 +y, 4 -z, 5 +z
+            voxel = n.link;
+            return true;
+        }
+    }
+    return oct_ray_iteration(nodes, oc, bx, by, bz, position, d, hit_pos, normal_code, voxel);
+}
+
+// Hittable for FastOctTree<Voxel> (fast_oct_tree/hittable.rs:10-68); `sr` is the object-space ray.
+__device__ bool octree_hit(const DOctNode* nodes, const DOctree& oc, const RayD& sr, D3 inv, double t_min, double t_max,
+                           double& t_out, int& sub, D3& pos_out) {
+    if (oc.n_nodes == 0) return false;
+    const double ws = (double)(1u << oc.world_log2);
+    if (!aabb_hit(D3{0.0, 0.0, 0.0}, D3{ws, ws, ws}, sr, inv, t_min, t_max)) return false;
+    D3 nd = normalize(sr.d);
+    D3 hp;
+    int ncode, voxel;
+    if (!oct_trace_ray(nodes, oc, sr.o, nd, hp, ncode, voxel)) return false;
+    D3 dp = hp - sr.o;
+    double t = sqrt(dot(dp, dp) / dot(sr.d, sr.d));
+    if (!(t > t_min && t < t_max)) return false;  // strict, unlike the other shapes
+    t_out = t;
+    sub = voxel * 6 + ncode;
+    pos_out = hp;
+    return true;
+}
+
+// Object::hit (hittable.rs:204-237) without the material: returns t and the sub-shape id.
+// `inv_world` = 1/direction of the world ray; objects with the identity transform use the world
+// ray as it is (the reference's M*(o+d) - M*o differs from d only by rounding).
+template <class OP, class SP>
+__device__ __forceinline__ bool object_hit(const SceneView& sv, OP ob, SP shapes, const RayD& ray, D3 inv_world,
+                                           double t_min, double t_max, const Rng& g, uint32_t medium_dim, double& t,
+                                           int& sub, D3& pos) {
+    RayD sr = ray;
+    D3 inv = inv_world;
+    if (!ob->identity) {
+        sr = xform_ray(&ob->to_object, false, ray);
+        inv = {rcp_fast(sr.d.x), rcp_fast(sr.d.y), rcp_fast(sr.d.z)};
+    }
+    SP sh = shapes + ob->shape;
+    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) {
+        sub = 0;
+        return medium_hit(shapes, sh, sr, inv, t_min, t_max, g, medium_dim, t);
+    }
+    if (sh->kind == MRT_SHAPE_OCTREE) return octree_hit(sv.oct_nodes, sv.octrees[sh->octree], sr, inv, t_min, t_max, t, sub, pos);
+    return solid_hit(sh, sr, inv, t_min, t_max, t, sub);
+}
+
 // Leaf box of a MovingSphere-based object for the time window (t0, t1) the reference passes
 // (bvh.rs:142-145,180; sphere.rs:175-186; hittable.rs:239-282).
 template <class OP, class SP>
@@ -363,7 +551,8 @@ __device__ void dynamic_leaf_box(OP ob, SP shapes, double t0, double t1, D3& mn,
 struct HitD {
     double t;
     int obj;
-    int sub;
+    int sub;   // RenderBox: face 0..5; octree: voxel * 6 + normal code
+    D3 pos;    // octree only: the DDA's hit position (the record's position, fast_oct_tree/hittable.rs:29-36)
 };
 
 // World::nearest_hit (world.rs:112-114) -> BvhTreeNode::hit (bvh.rs:135-167), stackless over the
@@ -375,6 +564,7 @@ __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng
     const double t_min = (double)0.001f;
     double closest = (double)FLT_MAX;
     int best_obj = -1, best_sub = 0;
+    D3 best_pos{0.0, 0.0, 0.0};
     uint32_t medium_ordinal = 0;
     D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
     int i = 0;
@@ -394,14 +584,14 @@ __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng
             const bool is_medium = sv.shapes[ob->shape].kind == MRT_SHAPE_CONSTANT_MEDIUM;
             double t;
             int sub;
-            if (object_hit(ob, sv.shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub)) {
+            if (object_hit(sv, ob, sv.shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
                 closest = t, best_obj = obj, best_sub = sub;
             }
             if (is_medium) medium_ordinal++;
             if (flags & NODE_TWICE) {
                 // second leaf of a span-1 node: box re-tested against the updated bound, new draw
                 if (aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
-                    if (object_hit(ob, sv.shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub)) {
+                    if (object_hit(sv, ob, sv.shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
                         closest = t, best_obj = obj, best_sub = sub;
                     }
                     medium_ordinal++;
@@ -413,6 +603,7 @@ __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng
     out.t = closest;
     out.obj = best_obj;
     out.sub = best_sub;
+    out.pos = best_pos;
     return best_obj >= 0;
 }
 
@@ -426,6 +617,7 @@ __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng
     const double t_min = (double)0.001f;
     double closest = (double)FLT_MAX;
     int best_obj = -1, best_sub = 0;
+    D3 best_pos{0.0, 0.0, 0.0};
     uint32_t medium_ordinal = 0;
     D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
     const int n = sv.n_nodes;
@@ -460,13 +652,13 @@ __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng
             if (pass) {
                 double t;
                 int sub;
-                if (object_hit(ob, shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub)) {
+                if (object_hit(sv, ob, shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
                     closest = t, best_obj = obj, best_sub = sub;
                 }
                 if (is_medium) medium_ordinal++;
                 if (flags & NODE_TWICE) {
                     if (aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
-                        if (object_hit(ob, shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub)) {
+                        if (object_hit(sv, ob, shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
                             closest = t, best_obj = obj, best_sub = sub;
                         }
                         medium_ordinal++;
@@ -479,6 +671,7 @@ __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng
     out.t = closest;
     out.obj = best_obj;
     out.sub = best_sub;
+    out.pos = best_pos;
     return best_obj >= 0;
 }
 
@@ -530,7 +723,7 @@ __device__ void surface_uv(SP sh, const Surface& s, double& u, double& v) {
     }
 }
 template <class OP, class SP>
-__device__ void surface_at(OP ob, SP shapes, const RayD& ray, double t, int sub, Surface& s) {
+__device__ void surface_at(OP ob, SP shapes, const RayD& ray, double t, int sub, D3 oct_pos, Surface& s) {
     RayD sr = ob->identity ? ray : xform_ray(&ob->to_object, false, ray);
     SP sh = shapes + ob->shape;
     auto p = sh->p;
@@ -550,6 +743,14 @@ __device__ void surface_at(OP ob, SP shapes, const RayD& ray, double t, int sub,
         case MRT_SHAPE_RENDER_BOX: {  // render_box.rs:21-93: "+" faces unflipped, "-" faces flipped
             double flip = (sub & 1) ? -1.0 : 1.0;
             s.n_obj = {sub >= 4 ? flip : 0.0, (sub == 2 || sub == 3) ? flip : 0.0, sub < 2 ? flip : 0.0};
+            break;
+        }
+        case MRT_SHAPE_OCTREE: {  // fast_oct_tree/hittable.rs:19-36: position from the walk, axis normal
+            int code = sub % 6;
+            double sg = (code & 1) ? 1.0 : -1.0;
+            s.n_obj = {code < 2 ? sg : 0.0, (code == 2 || code == 3) ? sg : 0.0, code >= 4 ? sg : 0.0};
+            s.pos_obj = oct_pos;
+            s.material = -1 - sub / 6;  // voxel record index, negative = VoxelMaterial::Lambertian
             break;
         }
         default:  // ConstantMedium: normal (1,0,0), front_face true for the phase function
@@ -762,7 +963,8 @@ __device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng&
         auto lob = lights + i;
         double t;
         int sub;
-        bool h = object_hit(lob, cshapes, ray, inv_d, ray.time, DBL_MAX, g, MRT_DIM_LIGHT_QUERY_MEDIUM + ordinal, t, sub);
+        D3 unused_pos;
+        bool h = object_hit(sv, lob, cshapes, ray, inv_d, ray.time, DBL_MAX, g, MRT_DIM_LIGHT_QUERY_MEDIUM + ordinal, t, sub, unused_pos);
         if (cshapes[lob->shape].kind == MRT_SHAPE_CONSTANT_MEDIUM) ordinal++;
         if (!h) continue;
         if (!any || !(best_t < t)) {  // reduce(|acc, x| if acc.t < x.t { acc } else { x })
@@ -772,7 +974,7 @@ __device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng&
     if (!any) return false;
     const DObject* ob = sv.lights + best;
     Surface s;
-    surface_at(ob, sv.shapes, ray, best_t, best_sub, s);
+    surface_at(ob, sv.shapes, ray, best_t, best_sub, D3{0.0, 0.0, 0.0}, s);
     D3 hit_pos = point_to_world(ob, s.pos_obj);
     D3 hit_n = normal_to_world(ob, s.n_obj);
     D3 to_light = hit_pos - ray.o;
@@ -932,7 +1134,7 @@ template <bool WAVE>
 __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, bool live, F3& radiance,
                              uint32_t& rays, uint32_t& light_queries) {
     radiance = {0.f, 0.f, 0.f};
-    HitD h{0.0, -1, 0};
+    HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     bool hit;
     if (WAVE) {
         hit = nearest_hit_wave(sv, ray, g, live, h);
@@ -948,16 +1150,25 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
     }
     const DObject* ob = sv.objects + h.obj;
     Surface s;
-    surface_at(ob, sv.shapes, ray, h.t, h.sub, s);
-    const DMaterial& m = sv.materials[s.material];
+    surface_at(ob, sv.shapes, ray, h.t, h.sub, h.pos, s);
+    // VoxelMaterial::Lambertian (fast_oct_tree/voxel.rs:85-90) behaves as Lambertian with a constant albedo
+    const bool voxel_mat = s.material < 0;
+    const DMaterial& m = sv.materials[voxel_mat ? 0 : s.material];
+    const int mkind = voxel_mat ? (int)MRT_MAT_LAMBERTIAN : m.kind;
     // HitRecord::new (hittable.rs:414-448): emit first, else scatter, else nothing.
-    switch (m.kind) {
+    switch (mkind) {
         case MRT_MAT_DIFFUSE_LIGHT: {  // material.rs:236-248
             if (s.front_face) radiance = thr * texture_color(sv, m.texture, sv.shapes + ob->shape, s);
             return false;
         }
         case MRT_MAT_LAMBERTIAN: {  // material.rs:54-64 + ray_tracer.rs:230-268
-            F3 att = texture_color(sv, m.texture, sv.shapes + ob->shape, s);
+            F3 att;
+            if (voxel_mat) {
+                const mrt_voxel& vx = sv.oct_voxels[-1 - s.material];
+                att = {vx.albedo[0], vx.albedo[1], vx.albedo[2]};
+            } else {
+                att = texture_color(sv, m.texture, sv.shapes + ob->shape, s);
+            }
             D3 pos_w = point_to_world(ob, s.pos_obj);
             D3 n_w = normal_to_world(ob, s.n_obj);
             D3 dir;
@@ -1170,14 +1381,14 @@ __global__ void __launch_bounds__(BLOCK) k_trace_rays(SceneView sv, const double
         ray = {{r[0], r[1], r[2]}, {r[3], r[4], r[5]}, r[6]};
     }
     Rng g{path_key(seed, (uint64_t)i, 0), 0};
-    HitD h{0.0, -1, 0};
+    HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     bool hit = WAVE ? nearest_hit_wave(sv, ray, g, live, h) : (live && nearest_hit_lane(sv, ray, g, h));
     if (!live) return;
     D3 n_w{0, 0, 0}, p_w{0, 0, 0};
     if (hit) {
         const DObject* ob = sv.objects + h.obj;
         Surface s;
-        surface_at(ob, sv.shapes, ray, h.t, h.sub, s);
+        surface_at(ob, sv.shapes, ray, h.t, h.sub, h.pos, s);
         n_w = normal_to_world(ob, s.n_obj);
         p_w = point_to_world(ob, s.pos_obj);
     }
@@ -1278,7 +1489,7 @@ int upload_scene(mrt_scene* sc) {
     UP(f.node_object, node_object) UP(f.node_skip, node_skip) UP(f.node_flags, node_flags)
     UP(f.objects, objects) UP(f.lights, lights) UP(f.shapes, shapes) UP(f.materials, materials)
     UP(f.textures, textures) UP(f.images, images) UP(f.image_pool, image_pool)
-    UP(f.octrees, octrees) UP(f.oct_nodes, oct_nodes) UP(f.oct_children, oct_children) UP(f.oct_voxels, oct_voxels)
+    UP(f.octrees, octrees) UP(f.oct_nodes, oct_nodes) UP(f.oct_voxels, oct_voxels)
 #undef UP
     v.n_nodes = (int32_t)f.node_object.size();
     v.n_objects = (int32_t)f.objects.size();

@@ -327,37 +327,46 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
             (o.n_children % 8) != 0)
             return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: bad arrays");
         DOctree dt{};
-        dt.root = o.root;
-        dt.node_offset = (uint32_t)s.oct_nodes.size();
-        dt.child_offset = (uint32_t)s.oct_children.size();
-        dt.voxel_offset = (uint32_t)s.oct_voxels.size();
         dt.n_nodes = o.n_nodes;
+        const uint32_t voxel_base = (uint32_t)s.oct_voxels.size();
         if (o.n_nodes) {
             if (o.root >= o.n_nodes) return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: bad root");
             dt.world_log2 = o.nodes[o.root].size;
             if (dt.world_log2 > 20) return fail(err, MRT_ERR_UNSUPPORTED, "octree: world larger than 2^20");
-        }
-        for (uint32_t k = 0; k < o.n_nodes; ++k) {
-            const mrt_oct_node& n = o.nodes[k];
-            if (n.kind == MRT_OCT_PARENT) {
-                if (n.first_child < 0 || (uint32_t)n.first_child + 8 > o.n_children || n.size == 0)
-                    return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: bad parent node");
-                for (int c = 0; c < 8; ++c) {
-                    uint32_t ci = o.children[(uint32_t)n.first_child + (uint32_t)c];
-                    if (ci >= o.n_nodes || o.nodes[ci].size + 1 != n.size)
-                        return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: bad child link");
+            // breadth-first re-linearisation from the root; validates links on the way
+            std::vector<uint32_t> order{o.root};
+            std::vector<uint8_t> seen(o.n_nodes, 0);
+            seen[o.root] = 1;
+            const uint32_t base = (uint32_t)s.oct_nodes.size();
+            dt.root = base;
+            for (size_t k = 0; k < order.size(); ++k) {
+                const mrt_oct_node& n = o.nodes[order[k]];
+                DOctNode dn{};
+                dn.kind_size = (uint32_t)n.kind | (n.size << 8);
+                dn.link = -1;
+                if (n.kind == MRT_OCT_PARENT) {
+                    if (n.first_child < 0 || (uint32_t)n.first_child + 8 > o.n_children || n.size == 0)
+                        return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: bad parent node");
+                    dn.link = (int32_t)(base + order.size());
+                    for (int c = 0; c < 8; ++c) {
+                        uint32_t ci = o.children[(uint32_t)n.first_child + (uint32_t)c];
+                        if (ci >= o.n_nodes || o.nodes[ci].size + 1 != n.size || seen[ci])
+                            return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: bad child link");
+                        seen[ci] = 1;
+                        order.push_back(ci);
+                    }
+                } else if (n.kind == MRT_OCT_LEAF) {
+                    if (n.voxel < 0 || (uint32_t)n.voxel >= o.n_voxels)
+                        return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: bad voxel index");
+                    if (o.voxels[n.voxel].kind != MRT_VOX_LAMBERTIAN)
+                        return fail(err, MRT_ERR_UNSUPPORTED, "octree: only solid Lambertian voxels are supported");
+                    dn.link = (int32_t)(voxel_base + (uint32_t)n.voxel);
+                } else if (n.kind != MRT_OCT_EMPTY) {
+                    return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: unknown node kind");
                 }
-            } else if (n.kind == MRT_OCT_LEAF) {
-                if (n.voxel < 0 || (uint32_t)n.voxel >= o.n_voxels)
-                    return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: bad voxel index");
-                if (o.voxels[n.voxel].kind != MRT_VOX_LAMBERTIAN)
-                    return fail(err, MRT_ERR_UNSUPPORTED, "octree: only solid Lambertian voxels are supported");
-            } else if (n.kind != MRT_OCT_EMPTY) {
-                return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: unknown node kind");
+                s.oct_nodes.push_back(dn);
             }
         }
-        s.oct_nodes.insert(s.oct_nodes.end(), o.nodes, o.nodes + o.n_nodes);
-        s.oct_children.insert(s.oct_children.end(), o.children, o.children + o.n_children);
         s.oct_voxels.insert(s.oct_voxels.end(), o.voxels, o.voxels + o.n_voxels);
         s.octrees.push_back(dt);
     }

@@ -54,13 +54,18 @@ struct DImage {
     uint64_t offset;  // float offset into the image pool
 };
 
+// Device octree node (8 bytes): nodes of one tree are stored breadth-first so that the eight
+// children of a parent are consecutive; `link` is the index of the first child (PARENT) or of the
+// voxel record (LEAF), both absolute indices into the shared pools.
+struct DOctNode {
+    uint32_t kind_size;  // kind | size << 8
+    int32_t link;
+};
 struct DOctree {
-    uint32_t root;
+    uint32_t root;         // absolute index of the root node
     uint32_t world_log2;   // root size (log2 of the world edge)
-    uint32_t node_offset;  // offsets into the shared octree pools
-    uint32_t child_offset;
-    uint32_t voxel_offset;
-    uint32_t n_nodes;
+    uint32_t n_nodes;      // 0: empty tree (no bounding box)
+    uint32_t pad;
 };
 
 // Camera::new output (camera.rs:44-76)
@@ -84,8 +89,7 @@ struct FlatScene {
     std::vector<DImage> images;
     std::vector<float> image_pool;
     std::vector<DOctree> octrees;
-    std::vector<mrt_oct_node> oct_nodes;
-    std::vector<uint32_t> oct_children;
+    std::vector<DOctNode> oct_nodes;
     std::vector<mrt_voxel> oct_voxels;
     DCamera camera;
     mrt_background background;

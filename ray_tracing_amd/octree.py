@@ -1,0 +1,235 @@
+"""Host-side construction of the linearised voxel octree handed to the C ABI.
+
+The reference builds `FastOctTree<Voxel>` by repeated `set` calls with leaf collapsing
+(cpu_rt/src/ray_tracer/hittable/fast_oct_tree/operations/set.rs:4-36, mod.rs:43-169) and loads
+MagicaVoxel files through dot_vox (operations/load.rs:74-127). Construction stays on the host; this
+module produces the same tree bottom-up from the final voxel set with numpy (a node whose eight
+children are equal leaves is one leaf, untouched regions are maximal empty nodes, the world edge is the
+smallest power of two above the largest coordinate ever set) and flattens it into the `mrt_octree`
+arrays. Only the query side (`trace_ray`, `ray_iteration`) runs on the GPU.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _ffi as F
+from .scene import VoxelGrid
+
+NODE_DTYPE = np.dtype([("kind", "<i4"), ("size", "<u4"), ("first_child", "<i4"), ("voxel", "<i4")])
+
+
+def from_color_hex(s: str) -> Tuple[float, float, float]:
+    """RgbColor::from_color_hex (cpu_rt/src/prelude/rgb_color.rs:92-126)."""
+    if not s.startswith("#") or len(s) < 7:
+        raise ValueError("invalid syntax")
+    total = int(s[1:7], 16)
+    f = np.float32
+    return (float(f((total >> 16) & 0xFF) / f(255.0)), float(f((total >> 8) & 0xFF) / f(255.0)),
+            float(f(total & 0xFF) / f(255.0)))
+
+
+class OctTree:
+    """A set of solid Lambertian voxels; later `set` calls overwrite earlier ones."""
+
+    def __init__(self):
+        self._coords: List[np.ndarray] = []
+        self._colors: List[np.ndarray] = []
+        self._max = -1
+
+    def set_many(self, coords: np.ndarray, albedo) -> None:
+        coords = np.asarray(coords, dtype=np.int64).reshape(-1, 3)
+        if len(coords) == 0:
+            return
+        if coords.min() < 0:
+            raise ValueError("negative voxel coordinate")
+        col = np.asarray(albedo, dtype=np.float32)
+        if col.ndim == 1:
+            col = np.broadcast_to(col, (len(coords), 3))
+        self._coords.append(coords)
+        self._colors.append(np.ascontiguousarray(col, dtype=np.float32))
+        self._max = max(self._max, int(coords.max()))
+
+    def set(self, albedo, position) -> None:
+        self.set_many(np.asarray([position]), albedo)
+
+    def voxels(self) -> Tuple[np.ndarray, np.ndarray]:
+        """Final (coords, colours) with overwrites resolved (last set wins)."""
+        if not self._coords:
+            return np.zeros((0, 3), np.int64), np.zeros((0, 3), np.float32)
+        c = np.concatenate(self._coords)
+        col = np.concatenate(self._colors)
+        key = (c[:, 0] << 42) | (c[:, 1] << 21) | c[:, 2]
+        # keep the LAST occurrence of every key
+        order = np.argsort(key[::-1], kind="stable")
+        rk = key[::-1][order]
+        first = np.ones(len(rk), dtype=bool)
+        first[1:] = rk[1:] != rk[:-1]
+        idx = (len(key) - 1 - order)[first]
+        return c[idx], col[idx]
+
+    def combine(self, other: "OctTree", offset) -> "OctTree":
+        """FastOctTree::combine (operations/combine.rs:4-19): other's voxels are set at +offset;
+        positions that become negative are dropped."""
+        c, col = other.voxels()
+        c = c + np.asarray(offset, dtype=np.int64)
+        keep = (c >= 0).all(axis=1)
+        self.set_many(c[keep], col[keep])
+        return self
+
+    def world_log2(self) -> Optional[int]:
+        if self._max < 0:
+            return None
+        k = 0
+        while (1 << k) <= self._max:
+            k += 1
+        return k
+
+    def world_size(self) -> int:
+        k = self.world_log2()
+        return 0 if k is None else 1 << k
+
+    def linearise(self) -> VoxelGrid:
+        """Bottom-up canonical octree -> (nodes, children, voxel table, root)."""
+        coords, colors = self.voxels()
+        k = self.world_log2()
+        if k is None:
+            raise ValueError("empty octree has no bounding box (hittable.rs:69-79 returns None)")
+        table, ids = np.unique(colors.view([("r", "<f4"), ("g", "<f4"), ("b", "<f4")]).reshape(-1), return_inverse=True)
+        voxel_table = np.stack([table["r"], table["g"], table["b"]], axis=1).astype(np.float32)
+        LEAF, PARENT, EMPTY = F.OCT_LEAF, F.OCT_PARENT, F.OCT_EMPTY
+        out_kind: List[np.ndarray] = []
+        out_size: List[np.ndarray] = []
+        out_fc: List[np.ndarray] = []
+        out_vox: List[np.ndarray] = []
+        children_blocks: List[np.ndarray] = []
+        n_nodes = 0
+        n_child_blocks = 0
+        # current level: one entry per occupied cell
+        cx, cy, cz = coords[:, 0].copy(), coords[:, 1].copy(), coords[:, 2].copy()
+        kind = np.full(len(coords), LEAF, dtype=np.int32)
+        payload = ids.astype(np.int64)          # leaf: voxel id; parent: first_child offset
+        for level in range(1, k + 1):
+            key = ((cx >> 1) << 42) | ((cy >> 1) << 21) | (cz >> 1)
+            slot = ((cx & 1) << 2) | ((cy & 1) << 1) | (cz & 1)
+            order = np.argsort(key, kind="stable")
+            key, slot, kind, payload = key[order], slot[order], kind[order], payload[order]
+            ukey, start = np.unique(key, return_index=True)
+            parent_of = np.searchsorted(ukey, key)
+            npar = len(ukey)
+            ck = np.full((npar, 8), EMPTY, dtype=np.int32)
+            cp = np.full((npar, 8), -1, dtype=np.int64)
+            ck[parent_of, slot] = kind
+            cp[parent_of, slot] = payload
+            collapse = (ck == LEAF).all(axis=1) & (cp == cp[:, :1]).all(axis=1)
+            keep = ~collapse
+            nk = int(keep.sum())
+            # emit the 8 child records of every surviving parent
+            ek, ep = ck[keep].reshape(-1), cp[keep].reshape(-1)
+            out_kind.append(ek)
+            out_size.append(np.full(len(ek), level - 1, dtype=np.uint32))
+            out_fc.append(np.where(ek == PARENT, ep, -1).astype(np.int32))
+            out_vox.append(np.where(ek == LEAF, ep, -1).astype(np.int32))
+            children_blocks.append((n_nodes + np.arange(len(ek))).astype(np.uint32))
+            first_child = (n_child_blocks + np.arange(nk)) * 8
+            n_nodes += len(ek)
+            n_child_blocks += nk
+            new_kind = np.where(collapse, LEAF, PARENT).astype(np.int32)
+            new_payload = cp[:, 0].copy()
+            new_payload[keep] = first_child
+            cx, cy, cz = ukey >> 42, (ukey >> 21) & ((1 << 21) - 1), ukey & ((1 << 21) - 1)
+            kind, payload = new_kind, new_payload
+        assert len(kind) == 1 and cx[0] == 0 and cy[0] == 0 and cz[0] == 0
+        out_kind.append(kind.astype(np.int32))
+        out_size.append(np.array([k], dtype=np.uint32))
+        out_fc.append(np.where(kind == PARENT, payload, -1).astype(np.int32))
+        out_vox.append(np.where(kind == LEAF, payload, -1).astype(np.int32))
+        nodes = np.zeros(n_nodes + 1, dtype=NODE_DTYPE)
+        nodes["kind"] = np.concatenate(out_kind)
+        nodes["size"] = np.concatenate(out_size)
+        nodes["first_child"] = np.concatenate(out_fc)
+        nodes["voxel"] = np.concatenate(out_vox)
+        children = np.concatenate(children_blocks) if children_blocks else np.zeros(0, np.uint32)
+        return VoxelGrid(nodes=nodes, children=children.astype(np.uint32), voxels=voxel_table, root=n_nodes)
+
+
+# ------------------------------------------------------------------ MagicaVoxel .vox (dot_vox 5.1.1 semantics)
+@dataclass
+class VoxFile:
+    models: List[np.ndarray]   # each (n, 4) uint8: x, y, z, i  (i = file colour index - 1)
+    palette: np.ndarray        # (256, 4) uint8 RGBA, entry i = i-th entry of the RGBA chunk
+
+
+def parse_vox(data: bytes) -> VoxFile:
+    if data[:4] != b"VOX ":
+        raise ValueError("not a .vox file")
+    pos = 8
+    models: List[np.ndarray] = []
+    palette = None
+
+    def read_chunk(p):
+        cid = data[p:p + 4]
+        n, m = struct.unpack_from("<ii", data, p + 4)
+        return cid, p + 12, n, m
+
+    cid, body, n, m = read_chunk(pos)
+    if cid != b"MAIN":
+        raise ValueError("missing MAIN chunk")
+    p, end = body + n, body + n + m
+    while p < end:
+        cid, body, n, m = read_chunk(p)
+        if cid == b"XYZI":
+            cnt = struct.unpack_from("<i", data, body)[0]
+            v = np.frombuffer(data, dtype=np.uint8, count=cnt * 4, offset=body + 4).reshape(-1, 4).copy()
+            v[:, 3] = v[:, 3] - 1     # dot_vox stores the file index minus one
+            models.append(v)
+        elif cid == b"RGBA":
+            palette = np.frombuffer(data, dtype=np.uint8, count=1024, offset=body).reshape(256, 4).copy()
+        p = body + n + m
+    if palette is None:
+        raise ValueError(".vox without an RGBA chunk (default palette) is not supported")
+    return VoxFile(models, palette)
+
+
+def load_vox(vox: VoxFile) -> OctTree:
+    """FastOctTree::load_vox (operations/load.rs:74-127): all models overlaid, scene-graph transforms
+    ignored, x = vx - min_x, y = vz - min_z, z = (max_y - min_y) - (vy - min_y)."""
+    allv = np.concatenate(vox.models).astype(np.int64)
+    mn, mx = allv[:, :3].min(axis=0), allv[:, :3].max(axis=0)
+    tree = OctTree()
+    for m in vox.models:
+        v = m.astype(np.int64)
+        pos = np.stack([v[:, 0] - mn[0], v[:, 2] - mn[2], -(v[:, 1] - mn[1]) + mx[1] - mn[1]], axis=1)
+        rgb = vox.palette[v[:, 3], :3].astype(np.float32) / np.float32(255.0)
+        tree.set_many(pos, rgb)
+    return tree
+
+
+def box_points(start, end) -> np.ndarray:
+    """IterBox::from_xyz(end).start_xyz(start) (cpu_rt/src/prelude.rs:19-77): x-major, z innermost."""
+    xs = np.arange(start[0], end[0])
+    ys = np.arange(start[1], end[1])
+    zs = np.arange(start[2], end[2])
+    if len(xs) == 0 or len(ys) == 0 or len(zs) == 0:
+        return np.zeros((0, 3), np.int64)
+    g = np.stack(np.meshgrid(xs, ys, zs, indexing="ij"), axis=-1).reshape(-1, 3)
+    return g.astype(np.int64)
+
+
+def city_grid(building: OctTree) -> OctTree:
+    """Geometry of `fast_oct_tree::city()` (cpu_rt/src/ray_tracer/world/fast_oct_tree.rs:818-883)."""
+    ROAD_WIDTH, ROAD_LENGTH, LINE_POSITION, CELL_SIZE, NUMBER_GRIDS = 9, 400, 4, 64, 5
+    line, road = from_color_hex("#e4af00"), from_color_hex("#363636")
+    grid = OctTree()
+    for i in range(NUMBER_GRIDS):
+        x_offset = i * (CELL_SIZE + ROAD_WIDTH)
+        pts = box_points((x_offset, 0, 0), (ROAD_WIDTH + x_offset, 1, ROAD_LENGTH))
+        col = np.where((pts[:, 0] == LINE_POSITION)[:, None], np.float32(line), np.float32(road))
+        grid.set_many(pts, col)
+        pts = box_points((0, 0, x_offset), (ROAD_LENGTH, 1, 20 + x_offset))
+        col = np.where((pts[:, 2] == LINE_POSITION)[:, None], np.float32(line), np.float32(road))
+        grid.set_many(pts, col)
+    return grid.combine(building, (ROAD_WIDTH, 1, ROAD_WIDTH))

@@ -15,7 +15,7 @@ import numpy as np
 
 from .scene import (CameraInfo, ConstantColor, ConstantMedium, Dielectric, DiffuseLight, ImageTexture, Isotropic,
                     Lambertian, Metal, MovingSphere, MultiplyTexture, Object, RenderBox, Sky, SolidColor, Sphere,
-                    Transform, WorldInfo, XYRect, XZRect, YZRect)
+                    SunSky, Transform, WorldInfo, XYRect, XZRect, YZRect)
 
 
 def _dist(a, b) -> float:
@@ -142,7 +142,47 @@ def synthetic_earthmap(width: int = 256, height: int = 128) -> np.ndarray:
     return np.stack([r, g, b], axis=-1).astype(np.float32)
 
 
+def fast_oct_tree_sphere() -> WorldInfo:
+    """world/fast_oct_tree.rs:13-62 ("Fast Oct Tree Sphere"): VoxelGrid::sphere(10) lit by a sphere light."""
+    from .octree import OctTree, box_points
+    radius = 10
+    pts = box_points((0, 0, 0), (2 * radius + 2,) * 3)
+    centre = np.array([radius, radius, radius], dtype=np.float64)
+    dist = np.sqrt((((pts + 0.5) - centre) ** 2).sum(axis=1))      # shapes/mod.rs:4-27
+    tree = OctTree()
+    tree.set_many(pts[dist <= radius], np.float32([0.5, 0.5, 0.5]))
+    origin, look_at = (-100.0, 10.0, 100.0), (10.0, 10.0, 10.0)
+    light = Object(Sphere(10.0, (-320.0, 100.0, -100.0), DiffuseLight(SolidColor((400.0, 400.0, 400.0)))))
+    return WorldInfo([Object(tree.linearise()), light], [Object(light.shape)], ConstantColor((0.1, 0.1, 0.1)),
+                     CameraInfo(1.0, 20.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
+def load_vox_fixture(path: str):
+    """Reads a decoded .vox fixture (tests/golden/*_vox.npz) back into a VoxFile."""
+    from .octree import VoxFile
+    z = np.load(path)
+    models, pos = [], 0
+    for n in z["model_sizes"]:
+        models.append(z["xyzi"][pos:pos + int(n)])
+        pos += int(n)
+    return VoxFile(models, z["palette"])
+
+
+def voxel_city(building_vox, scale_roads: bool = True) -> WorldInfo:
+    """Voxel-city configuration: geometry of `fast_oct_tree::city()` (world/fast_oct_tree.rs:818-883, built from
+    voxel_assets/city/skyscraper0.vox) with the camera and SunSky stored in examples/voxel_city_big.mscene
+    (the .mscene itself holds no geometry; its loader sets sun = None and no lights, save_file.rs:108-131)."""
+    from .octree import city_grid, load_vox
+    grid = city_grid(load_vox(building_vox))
+    bg = SunSky(intensity=0.05, sun_radius=0.08726646259971647, sun_theta=1.231, sun_phi=0.5235987755982988,
+                sun_brightness=22.0)
+    cam = CameraInfo(1.0, 40.0, (-150.0, 200.0, -150.0), (512.0, 10.0, 512.0), (0.0, 1.0, 0.0), 1e-05,
+                     955.2947189218623, 0.0, 0.0)
+    return WorldInfo([Object(grid.linearise())], [], bg, cam, sun=None)
+
+
 SCENARIOS: Dict[str, Callable[[], WorldInfo]] = {
+    "Fast Oct Tree Sphere": fast_oct_tree_sphere,
     "Cornell Smoke": cornell_smoke,
     "Easy Cornell Box": easy_cornell_box,
     "One Sphere": one_sphere,

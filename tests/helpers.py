@@ -7,7 +7,16 @@ from ray_tracing_amd import scenarios
 from ray_tracing_amd.scene import CameraInfo, Lambertian, Object, Sky, SolidColor, Sphere, WorldInfo
 
 
+import functools
+import os
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@functools.lru_cache(maxsize=None)
 def scene_by_name(name: str) -> WorldInfo:
+    if name == "Voxel City":
+        return scenarios.voxel_city(scenarios.load_vox_fixture(os.path.join(GOLDEN_DIR, "skyscraper0_vox.npz")))
     return scenarios.build(name)
 
 

@@ -21,7 +21,8 @@ from tests.helpers import probe_rays, rmse, scene_by_name
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SCENES = ["Cornell Smoke", "Random Scene", "Light Demonstration", "Easy Cornell Box", "Two Sphere"]
+SCENES = ["Cornell Smoke", "Random Scene", "Light Demonstration", "Easy Cornell Box", "Two Sphere",
+          "Fast Oct Tree Sphere", "Voxel City"]
 T_RTOL = 1e-5      # north star: within 1e-5 relative hit t and normals
 N_ATOL = 1e-5
 
@@ -151,7 +152,7 @@ def test_tier_p_image_vs_live_checker(worlds, name):
     np.testing.assert_allclose(m_g, m_o, rtol=2e-3, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["Cornell Smoke", "Random Scene", "Light Demonstration"])
+@pytest.mark.parametrize("name", ["Cornell Smoke", "Random Scene", "Light Demonstration", "Voxel City"])
 def test_tier_b_statistical_rmse(worlds, name):
     """RMSE protocol on linear pre-bloom radiance against an INDEPENDENT CPU estimator (mt19937_64)."""
     info, rt, ow = worlds(name, seed=3)

@@ -19,7 +19,7 @@ def bvh_equal(a, b):
 
 
 @pytest.mark.parametrize("name", ["Cornell Smoke", "Random Scene", "Light Demonstration", "Easy Cornell Box",
-                                  "One Sphere", "Two Sphere"])
+                                  "One Sphere", "Two Sphere", "Fast Oct Tree Sphere", "Voxel City"])
 def test_bvh_matches_checker_bit_for_bit(name):
     info = scene_by_name(name)
     assert bvh_equal(World(info, device=-1).bvh(), oracle_ffi.OracleWorld(info).bvh())

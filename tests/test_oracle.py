@@ -78,7 +78,7 @@ def test_cornell_bvh_shape():
 
 
 @pytest.mark.parametrize("name", ["Cornell Smoke", "Random Scene", "Light Demonstration", "Easy Cornell Box",
-                                  "Two Sphere"])
+                                  "Two Sphere", "Fast Oct Tree Sphere", "Voxel City"])
 def test_fixed_rays_and_render_golden(name):
     g = np.load(os.path.join(GOLD, name.lower().replace(" ", "_") + ".npz"))
     ow = oracle_ffi.OracleWorld(scene_by_name(name))
