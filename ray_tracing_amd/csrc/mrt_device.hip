@@ -84,6 +84,10 @@ struct RenderParams {
     uint32_t steps;
 };
 
+// Compile-time scene features: kernels are instantiated per feature set so that scenes without
+// an octree do not carry the voxel walk's registers.
+constexpr int FEAT_OCTREE = 1;
+
 // ============================================================== small vector math
 struct D3 {
     double x, y, z;
@@ -512,7 +516,7 @@ __device__ bool octree_hit(const DOctNode* nodes, const DOctree& oc, const RayD&
 // Object::hit (hittable.rs:204-237) without the material: returns t and the sub-shape id.
 // `inv_world` = 1/direction of the world ray; objects with the identity transform use the world
 // ray as it is (the reference's M*(o+d) - M*o differs from d only by rounding).
-template <class OP, class SP>
+template <int FEAT, class OP, class SP>
 __device__ __forceinline__ bool object_hit(const SceneView& sv, OP ob, SP shapes, const RayD& ray, D3 inv_world,
                                            double t_min, double t_max, const Rng& g, uint32_t medium_dim, double& t,
                                            int& sub, D3& pos) {
@@ -527,7 +531,10 @@ __device__ __forceinline__ bool object_hit(const SceneView& sv, OP ob, SP shapes
         sub = 0;
         return medium_hit(shapes, sh, sr, inv, t_min, t_max, g, medium_dim, t);
     }
-    if (sh->kind == MRT_SHAPE_OCTREE) return octree_hit(sv.oct_nodes, sv.octrees[sh->octree], sr, inv, t_min, t_max, t, sub, pos);
+    if constexpr ((FEAT & FEAT_OCTREE) != 0) {
+        if (sh->kind == MRT_SHAPE_OCTREE)
+            return octree_hit(sv.oct_nodes, sv.octrees[sh->octree], sr, inv, t_min, t_max, t, sub, pos);
+    }
     return solid_hit(sh, sr, inv, t_min, t_max, t, sub);
 }
 
@@ -560,6 +567,7 @@ struct HitD {
 // right result on ties is the same as keeping one running closest t and accepting t <= closest.
 //
 // Per-lane variant: every lane walks its own node sequence (large trees, incoherent rays).
+template <int FEAT>
 __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng& g, HitD& out) {
     const double t_min = (double)0.001f;
     double closest = (double)FLT_MAX;
@@ -584,14 +592,14 @@ __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng
             const bool is_medium = sv.shapes[ob->shape].kind == MRT_SHAPE_CONSTANT_MEDIUM;
             double t;
             int sub;
-            if (object_hit(sv, ob, sv.shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
+            if (object_hit<FEAT>(sv, ob, sv.shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
                 closest = t, best_obj = obj, best_sub = sub;
             }
             if (is_medium) medium_ordinal++;
             if (flags & NODE_TWICE) {
                 // second leaf of a span-1 node: box re-tested against the updated bound, new draw
                 if (aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
-                    if (object_hit(sv, ob, sv.shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
+                    if (object_hit<FEAT>(sv, ob, sv.shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
                         closest = t, best_obj = obj, best_sub = sub;
                     }
                     medium_ordinal++;
@@ -613,6 +621,7 @@ __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng
 // box test sits out until the walk leaves that subtree (`resume`); a subtree no lane wants is
 // skipped for the whole wave by a ballot. Must be called by every lane of the wave; lanes with
 // live == false only follow along.
+template <int FEAT>
 __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng& g, bool live, HitD& out) {
     const double t_min = (double)0.001f;
     double closest = (double)FLT_MAX;
@@ -652,13 +661,13 @@ __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng
             if (pass) {
                 double t;
                 int sub;
-                if (object_hit(sv, ob, shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
+                if (object_hit<FEAT>(sv, ob, shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
                     closest = t, best_obj = obj, best_sub = sub;
                 }
                 if (is_medium) medium_ordinal++;
                 if (flags & NODE_TWICE) {
                     if (aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
-                        if (object_hit(sv, ob, shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
+                        if (object_hit<FEAT>(sv, ob, shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
                             closest = t, best_obj = obj, best_sub = sub;
                         }
                         medium_ordinal++;
@@ -722,7 +731,7 @@ __device__ void surface_uv(SP sh, const Surface& s, double& u, double& v) {
         default: break;  // ConstantMedium: uv (0,0)
     }
 }
-template <class OP, class SP>
+template <int FEAT, class OP, class SP>
 __device__ void surface_at(OP ob, SP shapes, const RayD& ray, double t, int sub, D3 oct_pos, Surface& s) {
     RayD sr = ob->identity ? ray : xform_ray(&ob->to_object, false, ray);
     SP sh = shapes + ob->shape;
@@ -746,6 +755,7 @@ __device__ void surface_at(OP ob, SP shapes, const RayD& ray, double t, int sub,
             break;
         }
         case MRT_SHAPE_OCTREE: {  // fast_oct_tree/hittable.rs:19-36: position from the walk, axis normal
+            if constexpr ((FEAT & FEAT_OCTREE) == 0) break;
             int code = sub % 6;
             double sg = (code & 1) ? 1.0 : -1.0;
             s.n_obj = {code < 2 ? sg : 0.0, (code == 2 || code == 3) ? sg : 0.0, code >= 4 ? sg : 0.0};
@@ -964,7 +974,7 @@ __device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng&
         double t;
         int sub;
         D3 unused_pos;
-        bool h = object_hit(sv, lob, cshapes, ray, inv_d, ray.time, DBL_MAX, g, MRT_DIM_LIGHT_QUERY_MEDIUM + ordinal, t, sub, unused_pos);
+        bool h = object_hit<0>(sv, lob, cshapes, ray, inv_d, ray.time, DBL_MAX, g, MRT_DIM_LIGHT_QUERY_MEDIUM + ordinal, t, sub, unused_pos);
         if (cshapes[lob->shape].kind == MRT_SHAPE_CONSTANT_MEDIUM) ordinal++;
         if (!h) continue;
         if (!any || !(best_t < t)) {  // reduce(|acc, x| if acc.t < x.t { acc } else { x })
@@ -974,7 +984,7 @@ __device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng&
     if (!any) return false;
     const DObject* ob = sv.lights + best;
     Surface s;
-    surface_at(ob, sv.shapes, ray, best_t, best_sub, D3{0.0, 0.0, 0.0}, s);
+    surface_at<0>(ob, sv.shapes, ray, best_t, best_sub, D3{0.0, 0.0, 0.0}, s);
     D3 hit_pos = point_to_world(ob, s.pos_obj);
     D3 hit_n = normal_to_world(ob, s.n_obj);
     D3 to_light = hit_pos - ray.o;
@@ -1130,16 +1140,16 @@ __device__ __forceinline__ D3 reflect(D3 v, D3 n) { return v - 2.0 * dot(v, n) *
 // path's contribution (already multiplied by the throughput).
 // `live` marks the lanes that carry a path; with WAVE the traversal is wave-synchronous and every
 // lane of the wave must call this function.
-template <bool WAVE>
+template <bool WAVE, int FEAT>
 __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, bool live, F3& radiance,
                              uint32_t& rays, uint32_t& light_queries) {
     radiance = {0.f, 0.f, 0.f};
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     bool hit;
     if (WAVE) {
-        hit = nearest_hit_wave(sv, ray, g, live, h);
+        hit = nearest_hit_wave<FEAT>(sv, ray, g, live, h);
     } else {
-        hit = live && nearest_hit_lane(sv, ray, g, h);
+        hit = live && nearest_hit_lane<FEAT>(sv, ray, g, h);
     }
     if (!live) return false;
     rays++;
@@ -1150,9 +1160,9 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
     }
     const DObject* ob = sv.objects + h.obj;
     Surface s;
-    surface_at(ob, sv.shapes, ray, h.t, h.sub, h.pos, s);
+    surface_at<FEAT>(ob, sv.shapes, ray, h.t, h.sub, h.pos, s);
     // VoxelMaterial::Lambertian (fast_oct_tree/voxel.rs:85-90) behaves as Lambertian with a constant albedo
-    const bool voxel_mat = s.material < 0;
+    const bool voxel_mat = (FEAT & FEAT_OCTREE) != 0 && s.material < 0;
     const DMaterial& m = sv.materials[voxel_mat ? 0 : s.material];
     const int mkind = voxel_mat ? (int)MRT_MAT_LAMBERTIAN : m.kind;
     // HitRecord::new (hittable.rs:414-448): emit first, else scatter, else nothing.
@@ -1239,7 +1249,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // One launch = up to `steps` segments for every slot of the pool.
-template <bool WAVE>
+template <bool WAVE, int FEAT>
 __global__ void __launch_bounds__(BLOCK, SEG_WAVES_PER_SIMD) k_segments(SceneView sv, Pool pool, RenderParams rp, Counters* ctr) {
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     const bool in_range = slot < rp.n_slots;
@@ -1293,7 +1303,7 @@ __global__ void __launch_bounds__(BLOCK, SEG_WAVES_PER_SIMD) k_segments(SceneVie
         if (WAVE && !__any(live)) break;
         Rng g{key, (uint32_t)(live ? seg : 0)};
         F3 radiance;
-        bool cont = path_segment<WAVE>(sv, ray, thr, g, live, radiance, rays, light_queries);
+        bool cont = path_segment<WAVE, FEAT>(sv, ray, thr, g, live, radiance, rays, light_queries);
         if (live) {
             seg++;
             if (cont && seg >= 50) cont = false;  // depth 50 -> 0 returns BLACK (ray_tracer.rs:166-172, :451)
@@ -1369,7 +1379,7 @@ __global__ void __launch_bounds__(BLOCK) k_camera_rays(SceneView sv, uint32_t wi
     double* o = out + 7 * (size_t)i;
     o[0] = r.o.x, o[1] = r.o.y, o[2] = r.o.z, o[3] = r.d.x, o[4] = r.d.y, o[5] = r.d.z, o[6] = r.time;
 }
-template <bool WAVE>
+template <bool WAVE, int FEAT>
 __global__ void __launch_bounds__(BLOCK) k_trace_rays(SceneView sv, const double* rays, uint32_t n, uint64_t seed,
                                                       int32_t* obj_id, double* t_out, double* normal,
                                                       double* position, int32_t* front_face) {
@@ -1382,13 +1392,13 @@ __global__ void __launch_bounds__(BLOCK) k_trace_rays(SceneView sv, const double
     }
     Rng g{path_key(seed, (uint64_t)i, 0), 0};
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
-    bool hit = WAVE ? nearest_hit_wave(sv, ray, g, live, h) : (live && nearest_hit_lane(sv, ray, g, h));
+    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g, live, h) : (live && nearest_hit_lane<FEAT>(sv, ray, g, h));
     if (!live) return;
     D3 n_w{0, 0, 0}, p_w{0, 0, 0};
     if (hit) {
         const DObject* ob = sv.objects + h.obj;
         Surface s;
-        surface_at(ob, sv.shapes, ray, h.t, h.sub, h.pos, s);
+        surface_at<FEAT>(ob, sv.shapes, ray, h.t, h.sub, h.pos, s);
         n_w = normal_to_world(ob, s.n_obj);
         p_w = point_to_world(ob, s.pos_obj);
     }
@@ -1459,8 +1469,8 @@ struct mrt_scene {
     Counters* counters = nullptr;
     uint32_t pool_slots = 0;
     // options
-    int64_t opt_pool_slots = 1 << 22;
-    int64_t opt_steps = 4;
+    int64_t opt_pool_slots = 1 << 21;
+    int64_t opt_steps = 16;
     int64_t opt_trace_zero = 0;
     int64_t opt_compact = 1;
     int64_t opt_traversal = 0;  // 0 auto, 1 per-lane, 2 wave-synchronous
@@ -1579,12 +1589,18 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
         HIP_TRY(hipMemsetAsync(&sc->counters->live, 0, sizeof(unsigned int) * 2, stream));
         rp.n_slots = active;
         HIP_TRY(hipEventRecord(ek0, stream));
-        if (wave_sync)
-            hipLaunchKernelGGL(k_segments<true>, dim3((active + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, view,
-                               sc->pool[cur], rp, sc->counters);
-        else
-            hipLaunchKernelGGL(k_segments<false>, dim3((active + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, view,
-                               sc->pool[cur], rp, sc->counters);
+        {
+            const dim3 grid((active + BLOCK - 1) / BLOCK), block(BLOCK);
+            const bool oct = !sc->flat.octrees.empty();
+            if (wave_sync && !oct)
+                hipLaunchKernelGGL((k_segments<true, 0>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
+            else if (wave_sync && oct)
+                hipLaunchKernelGGL((k_segments<true, FEAT_OCTREE>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
+            else if (!oct)
+                hipLaunchKernelGGL((k_segments<false, 0>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
+            else
+                hipLaunchKernelGGL((k_segments<false, FEAT_OCTREE>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ek1, stream));
         HIP_TRY(hipMemcpyAsync(&host, sc->counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
@@ -1769,12 +1785,18 @@ int mrt_trace_rays(mrt_scene* scene, const double* rays, size_t n, uint64_t seed
     if (position && (rc = tmp.alloc(sizeof(double) * 3 * n, (void**)&dp)) != MRT_OK) return rc;
     if (front_face && (rc = tmp.alloc(sizeof(int32_t) * n, (void**)&dff)) != MRT_OK) return rc;
     HIP_TRY(hipMemcpy(drays, rays, sizeof(double) * 7 * n, hipMemcpyHostToDevice));
-    if (use_wave_sync(scene))
-        hipLaunchKernelGGL(k_trace_rays<true>, dim3(((uint32_t)n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, scene->view,
-                           drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
-    else
-        hipLaunchKernelGGL(k_trace_rays<false>, dim3(((uint32_t)n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, scene->view,
-                           drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
+    {
+        const dim3 grid(((uint32_t)n + BLOCK - 1) / BLOCK), block(BLOCK);
+        const bool oct = !scene->flat.octrees.empty(), ws = use_wave_sync(scene);
+        if (ws && !oct)
+            hipLaunchKernelGGL((k_trace_rays<true, 0>), grid, block, 0, 0, scene->view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
+        else if (ws && oct)
+            hipLaunchKernelGGL((k_trace_rays<true, FEAT_OCTREE>), grid, block, 0, 0, scene->view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
+        else if (!oct)
+            hipLaunchKernelGGL((k_trace_rays<false, 0>), grid, block, 0, 0, scene->view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
+        else
+            hipLaunchKernelGGL((k_trace_rays<false, FEAT_OCTREE>), grid, block, 0, 0, scene->view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     if (obj_id) HIP_TRY(hipMemcpy(obj_id, did, sizeof(int32_t) * n, hipMemcpyDeviceToHost));

@@ -1,0 +1,18 @@
+"""Throughput of every benchmark configuration (device-resident accumulation)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from ray_tracing_amd import scenarios, RayTracer
+from tests.helpers import scene_by_name
+
+for name, W, H, spp in [("Cornell Smoke", 1920, 1080, 64), ("Random Scene", 800, 450, 64),
+                        ("Light Demonstration", 1920, 1080, 64), ("Voxel City", 3840, 2160, 4),
+                        ("Fast Oct Tree Sphere", 1920, 1080, 16), ("Easy Cornell Box", 1920, 1080, 32)]:
+    rt = RayTracer(scene_by_name(name), device=0, seed=0)
+    accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    rt.render_device(accum.data_ptr(), W, H, 1)
+    accum.zero_()
+    st = rt.render_device(accum.data_ptr(), W, H, spp)
+    print(f"{name:22s} {W}x{H}x{spp}: Mpaths/s {st.paths / st.total_ms / 1e3:8.1f} Mrays/s {st.rays / st.total_ms / 1e3:8.1f} "
+          f"seg/path {st.rays / st.paths:.2f} launches {st.launches} total_ms {st.total_ms:.1f}", flush=True)

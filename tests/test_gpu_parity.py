@@ -271,3 +271,21 @@ def test_to_image_matches_checker(worlds, oracle):
     exp = np.zeros((48, 64, 3), dtype=np.uint8)
     oracle.oracle_to_image(img.ctypes.data, 64, 48, 4, exp.ctypes.data)
     assert (got == exp).all()
+
+
+def test_full_size_properties_voxel_city_4k(worlds):
+    """Voxel-city configuration at its stated size (3840x2160): size-independent properties."""
+    info, rt, ow = worlds("Voxel City", seed=3)
+    W, H = 3840, 2160
+    a, sa = gpu_render(rt, W, H, 2, first=0)
+    b, _ = gpu_render(rt, W, H, 1, first=0)
+    gpu_render(rt, W, H, 1, first=1, accum=b)
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)            # union of sample ranges
+    assert sa.paths == W * H * 2 and sa.paths <= sa.rays <= 50 * sa.paths
+    assert sa.light_queries == 0                                      # lights = [] (LightPdf::generate returns None)
+    assert np.isfinite(a).all() and a.min() >= 0.0 and a.max() <= 22.0 * 2 * 1.0001   # sun_brightness bounds radiance
+    ref, _ = ow.render(240, 135, 16, seed=5, threads=16)
+    np.testing.assert_allclose(a.mean(axis=(0, 1)) / 2, ref.mean(axis=(0, 1)) / 16, rtol=0.05)
+    # the sky above the skyline is the SunSky gradient: no geometry, exactly one ray per path there
+    top = a[H - 40:, :, :] / 2
+    assert top.min() > 0.0 and top.max() < 0.06
