@@ -148,7 +148,7 @@ def test_tier_p_image_vs_live_checker(worlds, name):
     assert off.mean() < 2e-3, f"{int(off.sum())} of {W * H} pixels differ"
     assert abs(st.rays - rst.rays) <= max(8, rst.rays // 2000)   # a flipped zero-throughput walk is up to 49 rays
     assert st.paths == rst.paths == W * H * spp
-    m_g, m_o = img.mean(axis=(0, 1)), ref.mean(axis=(0, 1))
+    m_g, m_o = img.mean(axis=(0, 1), dtype=np.float64), ref.mean(axis=(0, 1), dtype=np.float64)
     np.testing.assert_allclose(m_g, m_o, rtol=2e-3, atol=1e-5)
 
 
@@ -259,7 +259,8 @@ def test_full_size_properties_1080p(worlds):
     assert np.isfinite(a).all() and a.min() >= 0.0 and a.max() <= 7.0 * 4 * 1.0001
     # (4) image statistics agree with a low-resolution checker render of the same scene
     ref, _ = ow.render(240, 135, 32, seed=77, threads=16)
-    np.testing.assert_allclose(a.mean(axis=(0, 1)) / 4, ref.mean(axis=(0, 1)) / 32, rtol=0.03)
+    np.testing.assert_allclose(a.mean(axis=(0, 1), dtype=np.float64) / 4, ref.mean(axis=(0, 1), dtype=np.float64) / 32,
+                               rtol=0.03)
     # (5) the quirk columns: green wall / back wall black at full resolution
     assert a[400:700, 5:60].max() == 0.0 and a[500:560, 930:990].max() == 0.0
 
@@ -282,10 +283,12 @@ def test_full_size_properties_voxel_city_4k(worlds):
     gpu_render(rt, W, H, 1, first=1, accum=b)
     np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)            # union of sample ranges
     assert sa.paths == W * H * 2 and sa.paths <= sa.rays <= 50 * sa.paths
-    assert sa.light_queries == 0                                      # lights = [] (LightPdf::generate returns None)
+    assert 0 < sa.light_queries <= sa.rays                            # LightPdf::value still queries the (empty) light list
     assert np.isfinite(a).all() and a.min() >= 0.0 and a.max() <= 22.0 * 2 * 1.0001   # sun_brightness bounds radiance
-    ref, _ = ow.render(240, 135, 16, seed=5, threads=16)
-    np.testing.assert_allclose(a.mean(axis=(0, 1)) / 2, ref.mean(axis=(0, 1)) / 16, rtol=0.05)
+    # (means in f64: a float32 running sum over 8.3 M pixels loses several per cent)
+    ref, _ = ow.render(240, 135, 32, seed=5, threads=16)
+    np.testing.assert_allclose(a.mean(axis=(0, 1), dtype=np.float64) / 2, ref.mean(axis=(0, 1), dtype=np.float64) / 32,
+                               rtol=0.02)
     # the sky above the skyline is the SunSky gradient: no geometry, exactly one ray per path there
-    top = a[H - 40:, :, :] / 2
+    top = a[H - 40:, :400, :] / 2
     assert top.min() > 0.0 and top.max() < 0.06
