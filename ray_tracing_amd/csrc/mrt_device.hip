@@ -39,6 +39,7 @@ struct SceneView {
     const int32_t* node_object;
     const int32_t* node_skip;
     const int32_t* node_flags;
+    const DNodeRec* node_recs;
     int32_t n_nodes;
     int32_t n_objects;
     int32_t n_lights;
@@ -264,12 +265,11 @@ __device__ __forceinline__ bool box_hit(PP p, const RayD& r, D3 inv, double t_mi
 }
 
 // Deterministic shapes (everything a ConstantMedium may wrap). `sub` = box face.
-template <class SP>
-__device__ __forceinline__ bool solid_hit(SP sh, const RayD& r, D3 inv, double t_min, double t_max, double& t,
-                                          int& sub) {
-    auto p = sh->p;
+template <class PP>
+__device__ __forceinline__ bool solid_hit_kp(int kind, PP p, const RayD& r, D3 inv, double t_min, double t_max,
+                                             double& t, int& sub) {
     sub = 0;
-    switch (sh->kind) {
+    switch (kind) {
         case MRT_SHAPE_SPHERE: return sphere_hit(D3{p[1], p[2], p[3]}, p[0], r, t_min, t_max, t);
         case MRT_SHAPE_MOVING_SPHERE: return sphere_hit(moving_center(p, r.time), p[0], r, t_min, t_max, t);
         case MRT_SHAPE_XY_RECT: return rect_hit<2>(p[0], p[1], p[2], p[3], p[4], r, inv, t_min, t_max, t);
@@ -279,16 +279,20 @@ __device__ __forceinline__ bool solid_hit(SP sh, const RayD& r, D3 inv, double t
         default: return false;
     }
 }
+template <class SP>
+__device__ __forceinline__ bool solid_hit(SP sh, const RayD& r, D3 inv, double t_min, double t_max, double& t,
+                                          int& sub) {
+    return solid_hit_kp(sh->kind, sh->p, r, inv, t_min, t_max, t, sub);
+}
 
 // constant_medium.rs:35-93. One uniform draw at dimension `dim`.
-template <class SP>
-__device__ __forceinline__ bool medium_hit(SP shapes, SP sh, const RayD& r, D3 inv, double t_min, double t_max,
-                                           const Rng& g, uint32_t dim, double& t_out) {
-    SP bnd = shapes + sh->boundary;
+template <class PP>
+__device__ __forceinline__ bool medium_core(int bkind, PP bp, double neg_inv_density, const RayD& r, D3 inv,
+                                            double t_min, double t_max, const Rng& g, uint32_t dim, double& t_out) {
     double t1, t2;
     int s;
-    if (!solid_hit(bnd, r, inv, -10000000000.0, 10000000000.0, t1, s)) return false;
-    if (!solid_hit(bnd, r, inv, t1 + 0.0001, 10000000000.0, t2, s)) return false;
+    if (!solid_hit_kp(bkind, bp, r, inv, -10000000000.0, 10000000000.0, t1, s)) return false;
+    if (!solid_hit_kp(bkind, bp, r, inv, t1 + 0.0001, 10000000000.0, t2, s)) return false;
     if (t1 < t_min) t1 = t_min;
     if (t2 > t_max) t2 = t_max;
     if (t1 >= t2) return false;
@@ -296,11 +300,16 @@ __device__ __forceinline__ bool medium_hit(SP shapes, SP sh, const RayD& r, D3 i
     double len2 = r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z;
     double ray_length = sqrt(len2);
     double distance_inside = (t2 - t1) * ray_length;
-    double neg_inv_density = -1.0 / sh->p[0];
     double hit_distance = neg_inv_density * log(rand_scalar(g, 0.0, 1.0, dim));
     if (hit_distance > distance_inside) return false;
     t_out = t1 + hit_distance * rcp_fast(ray_length);
     return true;
+}
+template <class SP>
+__device__ __forceinline__ bool medium_hit(SP shapes, SP sh, const RayD& r, D3 inv, double t_min, double t_max,
+                                           const Rng& g, uint32_t dim, double& t_out) {
+    SP bnd = shapes + sh->boundary;
+    return medium_core(bnd->kind, bnd->p, -1.0 / sh->p[0], r, inv, t_min, t_max, g, dim, t_out);
 }
 
 // Aabb::hit (bvh.rs:18-33): every axis is tested on its own against the ORIGINAL [t_min, t_max].
@@ -538,6 +547,31 @@ __device__ __forceinline__ bool object_hit(const SceneView& sv, OP ob, SP shapes
     return solid_hit(sh, sr, inv, t_min, t_max, t, sub);
 }
 
+// Leaf test of the wave-synchronous walk from a self-contained node record (scalar operands);
+// records that are not `simple` fall back to the object tables.
+template <int FEAT, class RP>
+__device__ __forceinline__ bool node_hit(const SceneView& sv, RP r, const RayD& ray, D3 inv_world, double t_min,
+                                         double t_max, const Rng& g, uint32_t medium_dim, double& t, int& sub, D3& pos) {
+    if (!r->simple)
+        return object_hit<FEAT>(sv, as_const(sv.objects) + r->object, as_const(sv.shapes), ray, inv_world, t_min, t_max,
+                                g, medium_dim, t, sub, pos);
+    RayD sr = ray;
+    D3 inv = inv_world;
+    if (!r->identity) {
+        sr = xform_ray(&r->to_object, false, ray);
+        inv = {rcp_fast(sr.d.x), rcp_fast(sr.d.y), rcp_fast(sr.d.z)};
+    }
+    const int kind = r->kind;
+    if (kind == MRT_SHAPE_CONSTANT_MEDIUM) {
+        sub = 0;
+        return medium_core(r->kind2, r->p, r->p[9], sr, inv, t_min, t_max, g, medium_dim, t);
+    }
+    if constexpr ((FEAT & FEAT_OCTREE) != 0) {
+        if (kind == MRT_SHAPE_OCTREE) return octree_hit(sv.oct_nodes, sv.octrees[r->octree], sr, inv, t_min, t_max, t, sub, pos);
+    }
+    return solid_hit_kp(kind, r->p, sr, inv, t_min, t_max, t, sub);
+}
+
 // Leaf box of a MovingSphere-based object for the time window (t0, t1) the reference passes
 // (bvh.rs:142-145,180; sphere.rs:175-186; hittable.rs:239-282).
 template <class OP, class SP>
@@ -630,24 +664,20 @@ __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng
     uint32_t medium_ordinal = 0;
     D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
     const int n = sv.n_nodes;
-    auto node_object = as_const(sv.node_object);
-    auto node_skip = as_const(sv.node_skip);
-    auto node_flags = as_const(sv.node_flags);
-    auto bmin_x = as_const(sv.bmin_x), bmin_y = as_const(sv.bmin_y), bmin_z = as_const(sv.bmin_z);
-    auto bmax_x = as_const(sv.bmax_x), bmax_y = as_const(sv.bmax_y), bmax_z = as_const(sv.bmax_z);
-    auto objects = as_const(sv.objects);
-    auto shapes = as_const(sv.shapes);
+    auto recs = as_const(sv.node_recs);
     int resume = live ? 0 : n;
     int i = 0;
     while (i < n) {
-        const int obj = node_object[i];
-        const int flags = node_flags[i];
-        const int skip = node_skip[i];
-        D3 mn{bmin_x[i], bmin_y[i], bmin_z[i]};
-        D3 mx{bmax_x[i], bmax_y[i], bmax_z[i]};
+        auto r = recs + i;  // wave-uniform: every field below is a scalar load
+        const int obj = r->object;
+        const int flags = r->flags;
+        const int skip = r->skip;
+        D3 mn{r->bmin[0], r->bmin[1], r->bmin[2]};
+        D3 mx{r->bmax[0], r->bmax[1], r->bmax[2]};
         bool pass = false;
         if (i >= resume) {
-            if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(objects + obj, shapes, t_min, closest, mn, mx);
+            if (flags & NODE_DYNAMIC_BOX)
+                dynamic_leaf_box(as_const(sv.objects) + obj, as_const(sv.shapes), t_min, closest, mn, mx);
             pass = aabb_hit(mn, mx, ray, inv_d, t_min, closest);
             if (!pass) resume = skip;
         }
@@ -655,23 +685,20 @@ __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng
             i = skip;
             continue;
         }
-        if (obj >= 0) {
-            auto ob = objects + obj;
-            const bool is_medium = shapes[ob->shape].kind == MRT_SHAPE_CONSTANT_MEDIUM;
-            if (pass) {
-                double t;
-                int sub;
-                if (object_hit<FEAT>(sv, ob, shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
-                    closest = t, best_obj = obj, best_sub = sub;
-                }
-                if (is_medium) medium_ordinal++;
-                if (flags & NODE_TWICE) {
-                    if (aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
-                        if (object_hit<FEAT>(sv, ob, shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
-                            closest = t, best_obj = obj, best_sub = sub;
-                        }
-                        medium_ordinal++;
+        if (obj >= 0 && pass) {
+            const bool is_medium = r->kind == MRT_SHAPE_CONSTANT_MEDIUM;
+            double t;
+            int sub;
+            if (node_hit<FEAT>(sv, r, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
+                closest = t, best_obj = obj, best_sub = sub;
+            }
+            if (is_medium) medium_ordinal++;
+            if (flags & NODE_TWICE) {
+                if (aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
+                    if (node_hit<FEAT>(sv, r, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
+                        closest = t, best_obj = obj, best_sub = sub;
                     }
+                    medium_ordinal++;
                 }
             }
         }
@@ -1138,21 +1165,11 @@ __device__ __forceinline__ D3 reflect(D3 v, D3 n) { return v - 2.0 * dot(v, n) *
 // "throughput *= attenuation [/ value]"; the terminal value is emitted light, background or black.
 // Returns true when the path continues with `ray` / `thr` updated; otherwise `radiance` holds the
 // path's contribution (already multiplied by the throughput).
-// `live` marks the lanes that carry a path; with WAVE the traversal is wave-synchronous and every
-// lane of the wave must call this function.
-template <bool WAVE, int FEAT>
-__device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, bool live, F3& radiance,
-                             uint32_t& rays, uint32_t& light_queries) {
+// Material response at the nearest hit `h` (or the background when `hit` is false).
+template <int FEAT>
+__device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, const HitD& h, bool hit,
+                            F3& radiance, uint32_t& light_queries) {
     radiance = {0.f, 0.f, 0.f};
-    HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
-    bool hit;
-    if (WAVE) {
-        hit = nearest_hit_wave<FEAT>(sv, ray, g, live, h);
-    } else {
-        hit = live && nearest_hit_lane<FEAT>(sv, ray, g, h);
-    }
-    if (!live) return false;
-    rays++;
     if (!hit) {
         F3 bg = background_color(sv, ray);
         radiance = thr * bg;
@@ -1235,6 +1252,49 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
     if (!sv.trace_zero_throughput && thr.r == 0.f && thr.g == 0.f && thr.b == 0.f) return false;
     return true;
 }
+
+// One segment for one lane: nearest hit + material response. `live` marks the lanes that carry a
+// path; with WAVE the traversal is wave-synchronous and every lane of the wave must call this.
+template <bool WAVE, int FEAT>
+__device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, bool live, F3& radiance,
+                             uint32_t& rays, uint32_t& light_queries) {
+    radiance = {0.f, 0.f, 0.f};
+    HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
+    bool hit;
+    if (WAVE) {
+        hit = nearest_hit_wave<FEAT>(sv, ray, g, live, h);
+    } else {
+        hit = live && nearest_hit_lane<FEAT>(sv, ray, g, h);
+    }
+    if (!live) return false;
+    rays++;
+    return shade_stage<FEAT>(sv, ray, thr, g, h, hit, radiance, light_queries);
+}
+
+// Shading class of a lane after the nearest-hit query; lanes of one class run the same code.
+enum : int { CLS_LAMB_COS = 0, CLS_LAMB_LIGHT = 1, CLS_LAMB_SKY = 2, CLS_SPECULAR = 3, CLS_TERMINAL = 4, CLS_DEAD = 5, N_CLS = 6 };
+template <int FEAT>
+__device__ __forceinline__ int shading_class(const SceneView& sv, const Rng& g, const HitD& h, bool live, bool hit) {
+    if (!live) return CLS_DEAD;
+    if (!hit) return CLS_TERMINAL;
+    const DShape& sh = sv.shapes[sv.objects[h.obj].shape];
+    int kind = MRT_MAT_LAMBERTIAN;
+    if (!((FEAT & FEAT_OCTREE) != 0 && sh.kind == MRT_SHAPE_OCTREE)) kind = sv.materials[sh.material].kind;
+    if (kind == MRT_MAT_LAMBERTIAN) return (int)rand_u32(g, 0, 3, MRT_DIM_PDF_CHOICE);  // pdf.rs:240
+    if (kind == MRT_MAT_DIFFUSE_LIGHT) return CLS_TERMINAL;
+    return CLS_SPECULAR;
+}
+
+// LDS image for the workgroup-local sort of path states (one slot per thread).
+template <int FEAT>
+struct SortLds {
+    static constexpr int ND = (FEAT & FEAT_OCTREE) ? 11 : 8;
+    double d[ND][256];     // ray origin, direction, time, hit t (+ octree hit position)
+    uint64_t key[256];
+    float f[3][256];       // throughput
+    uint32_t u[4][256];    // pixel, seg, obj, sub
+    uint32_t cnt[4][8];    // per wave, per class
+};
 
 // ============================================================== kernels
 constexpr int BLOCK = 256;
@@ -1334,6 +1394,146 @@ __global__ void __launch_bounds__(BLOCK, SEG_WAVES_PER_SIMD) k_segments(SceneVie
     light_queries = wave_sum(light_queries);
     if (lane_id() == 0) {
         if (live) atomicAdd(&ctr->live, live);
+        if (rays) atomicAdd(&ctr->rays, (unsigned long long)rays);
+        if (light_queries) atomicAdd(&ctr->light_queries, (unsigned long long)light_queries);
+    }
+}
+
+// Variant of k_segments with a workgroup-local sort: after the nearest-hit query the 256 path
+// states of the workgroup are redistributed through LDS by shading class (counting sort: wave
+// ballots + popcounts, per-wave counts in LDS), so each wave shades (mostly) one class and dead
+// lanes gather in the last waves. Slots are anonymous, so states never move back.
+// Requires n_slots to be a multiple of the workgroup size.
+template <bool WAVE, int FEAT>
+__global__ void __launch_bounds__(BLOCK, SEG_WAVES_PER_SIMD) k_segments_sorted(SceneView sv, Pool pool, RenderParams rp,
+                                                                            Counters* ctr) {
+    __shared__ SortLds<FEAT> lds;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t slot = blockIdx.x * BLOCK + tid;
+    const uint32_t wave = tid >> 6;
+    int32_t seg = pool.seg[slot];
+    RayD ray{{0, 0, 0}, {0, 0, 1}, 0};
+    F3 thr{0.f, 0.f, 0.f};
+    uint32_t pixel = 0;
+    uint64_t key = 0;
+    if (seg >= 0) {
+        ray.o = {pool.ox[slot], pool.oy[slot], pool.oz[slot]};
+        ray.d = {pool.dx[slot], pool.dy[slot], pool.dz[slot]};
+        ray.time = pool.tm[slot];
+        thr = {pool.tr[slot], pool.tg[slot], pool.tb[slot]};
+        pixel = pool.pixel[slot];
+        key = pool.key[slot];
+    }
+    uint32_t rays = 0, light_queries = 0;
+    bool exhausted = false;
+    for (uint32_t step = 0; step < rp.steps; ++step) {
+        // ---- regeneration (as in k_segments)
+        bool want = seg < 0 && !exhausted;
+        unsigned long long mask = __ballot(want);
+        if (mask) {
+            uint32_t n_want = (uint32_t)__popcll(mask);
+            unsigned long long base = 0;
+            int leader = __ffsll((long long)mask) - 1;
+            if ((int)lane_id() == leader) base = atomicAdd(&ctr->work_next, (unsigned long long)n_want);
+            base = __shfl(base, leader, 64);
+            if (want) {
+                unsigned long long w = base + (unsigned long long)__popcll(mask & ((1ULL << lane_id()) - 1ULL));
+                if (w < rp.n_work) {
+                    unsigned long long sample = w / rp.npix_strip;
+                    uint32_t pl = (uint32_t)(w - sample * rp.npix_strip);
+                    uint32_t y = pl / rp.strip_w;
+                    uint32_t x = rp.x0 + (pl - y * rp.strip_w);
+                    pixel = x + y * rp.width;
+                    key = path_key(rp.seed, (uint64_t)pixel, rp.first_sample + sample);
+                    Rng g0{key, 0};
+                    ray = camera_ray(sv, x, y, rp.width, rp.height, g0);
+                    thr = {1.f, 1.f, 1.f};
+                    seg = 0;
+                } else {
+                    exhausted = true;
+                }
+            }
+        }
+        bool live = seg >= 0;
+        if (!__syncthreads_or(live ? 1 : 0)) break;  // block-uniform exit; also fences the LDS image
+
+        // ---- nearest hit
+        Rng g{key, (uint32_t)(live ? seg : 0)};
+        HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
+        bool hit;
+        if (WAVE) hit = nearest_hit_wave<FEAT>(sv, ray, g, live, h);
+        else hit = live && nearest_hit_lane<FEAT>(sv, ray, g, h);
+        if (live) rays++;
+
+        // ---- counting sort by shading class
+        const int cls = shading_class<FEAT>(sv, g, h, live, hit);
+        uint32_t rank = 0;
+        unsigned long long my_mask = 0;
+#pragma unroll
+        for (int c = 0; c < N_CLS; ++c) {
+            unsigned long long m = __ballot(cls == c);
+            if (lane_id() == 0) lds.cnt[wave][c] = (uint32_t)__popcll(m);
+            if (cls == c) my_mask = m;
+        }
+        rank = (uint32_t)__popcll(my_mask & ((1ULL << lane_id()) - 1ULL));
+        __syncthreads();
+        uint32_t dst = rank;
+#pragma unroll
+        for (int c = 0; c < N_CLS; ++c) {
+#pragma unroll
+            for (int w = 0; w < BLOCK / 64; ++w) {
+                uint32_t n = lds.cnt[w][c];
+                if (c < cls || (c == cls && (uint32_t)w < wave)) dst += n;
+            }
+        }
+        lds.d[0][dst] = ray.o.x, lds.d[1][dst] = ray.o.y, lds.d[2][dst] = ray.o.z;
+        lds.d[3][dst] = ray.d.x, lds.d[4][dst] = ray.d.y, lds.d[5][dst] = ray.d.z;
+        lds.d[6][dst] = ray.time, lds.d[7][dst] = h.t;
+        if constexpr ((FEAT & FEAT_OCTREE) != 0) lds.d[8][dst] = h.pos.x, lds.d[9][dst] = h.pos.y, lds.d[10][dst] = h.pos.z;
+        lds.key[dst] = key;
+        lds.f[0][dst] = thr.r, lds.f[1][dst] = thr.g, lds.f[2][dst] = thr.b;
+        lds.u[0][dst] = pixel, lds.u[1][dst] = (uint32_t)seg, lds.u[2][dst] = (uint32_t)(hit ? h.obj : -1), lds.u[3][dst] = (uint32_t)h.sub;
+        __syncthreads();
+        ray.o = {lds.d[0][tid], lds.d[1][tid], lds.d[2][tid]};
+        ray.d = {lds.d[3][tid], lds.d[4][tid], lds.d[5][tid]};
+        ray.time = lds.d[6][tid], h.t = lds.d[7][tid];
+        if constexpr ((FEAT & FEAT_OCTREE) != 0) h.pos = {lds.d[8][tid], lds.d[9][tid], lds.d[10][tid]};
+        key = lds.key[tid];
+        thr = {lds.f[0][tid], lds.f[1][tid], lds.f[2][tid]};
+        pixel = lds.u[0][tid], seg = (int32_t)lds.u[1][tid], h.obj = (int32_t)lds.u[2][tid], h.sub = (int32_t)lds.u[3][tid];
+        live = seg >= 0;
+        hit = h.obj >= 0;
+
+        // ---- material response
+        if (live) {
+            Rng g2{key, (uint32_t)seg};
+            F3 radiance;
+            bool cont = shade_stage<FEAT>(sv, ray, thr, g2, h, hit, radiance, light_queries);
+            seg++;
+            if (cont && seg >= 50) cont = false;
+            if (!cont) {
+                float* px = rp.accum + (size_t)pixel * 3;
+                if (radiance.r != 0.f) atomicAdd(px + 0, radiance.r);
+                if (radiance.g != 0.f) atomicAdd(px + 1, radiance.g);
+                if (radiance.b != 0.f) atomicAdd(px + 2, radiance.b);
+                seg = -1;
+            }
+        }
+    }
+    pool.seg[slot] = seg;
+    if (seg >= 0) {
+        pool.ox[slot] = ray.o.x, pool.oy[slot] = ray.o.y, pool.oz[slot] = ray.o.z;
+        pool.dx[slot] = ray.d.x, pool.dy[slot] = ray.d.y, pool.dz[slot] = ray.d.z;
+        pool.tm[slot] = ray.time;
+        pool.tr[slot] = thr.r, pool.tg[slot] = thr.g, pool.tb[slot] = thr.b;
+        pool.pixel[slot] = pixel;
+        pool.key[slot] = key;
+    }
+    uint32_t live_n = wave_sum(seg >= 0 ? 1u : 0u);
+    rays = wave_sum(rays);
+    light_queries = wave_sum(light_queries);
+    if (lane_id() == 0) {
+        if (live_n) atomicAdd(&ctr->live, live_n);
         if (rays) atomicAdd(&ctr->rays, (unsigned long long)rays);
         if (light_queries) atomicAdd(&ctr->light_queries, (unsigned long long)light_queries);
     }
@@ -1474,6 +1674,7 @@ struct mrt_scene {
     int64_t opt_trace_zero = 0;
     int64_t opt_compact = 1;
     int64_t opt_traversal = 0;  // 0 auto, 1 per-lane, 2 wave-synchronous
+    int64_t opt_sort = 0;       // workgroup-local sort by shading class
     std::mutex mu;
 };
 
@@ -1496,7 +1697,7 @@ int upload_scene(mrt_scene* sc) {
     if ((rc = m.upload(vec, &v.field)) != MRT_OK) return rc;
     UP(f.bmin[0], bmin_x) UP(f.bmin[1], bmin_y) UP(f.bmin[2], bmin_z)
     UP(f.bmax[0], bmax_x) UP(f.bmax[1], bmax_y) UP(f.bmax[2], bmax_z)
-    UP(f.node_object, node_object) UP(f.node_skip, node_skip) UP(f.node_flags, node_flags)
+    UP(f.node_object, node_object) UP(f.node_skip, node_skip) UP(f.node_flags, node_flags) UP(f.node_recs, node_recs)
     UP(f.objects, objects) UP(f.lights, lights) UP(f.shapes, shapes) UP(f.materials, materials)
     UP(f.textures, textures) UP(f.images, images) UP(f.image_pool, image_pool)
     UP(f.octrees, octrees) UP(f.oct_nodes, oct_nodes) UP(f.oct_voxels, oct_voxels)
@@ -1592,7 +1793,16 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
         {
             const dim3 grid((active + BLOCK - 1) / BLOCK), block(BLOCK);
             const bool oct = !sc->flat.octrees.empty();
-            if (wave_sync && !oct)
+            if (sc->opt_sort && (active % BLOCK) == 0) {
+                if (wave_sync && !oct)
+                    hipLaunchKernelGGL((k_segments_sorted<true, 0>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
+                else if (wave_sync && oct)
+                    hipLaunchKernelGGL((k_segments_sorted<true, FEAT_OCTREE>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
+                else if (!oct)
+                    hipLaunchKernelGGL((k_segments_sorted<false, 0>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
+                else
+                    hipLaunchKernelGGL((k_segments_sorted<false, FEAT_OCTREE>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
+            } else if (wave_sync && !oct)
                 hipLaunchKernelGGL((k_segments<true, 0>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
             else if (wave_sync && oct)
                 hipLaunchKernelGGL((k_segments<true, FEAT_OCTREE>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
@@ -1731,6 +1941,8 @@ int mrt_scene_set_option(mrt_scene* scene, const char* name, int64_t value) {
         scene->opt_trace_zero = value ? 1 : 0;
     } else if (n == "compaction") {
         scene->opt_compact = value ? 1 : 0;
+    } else if (n == "sort") {
+        scene->opt_sort = value ? 1 : 0;
     } else if (n == "traversal") {
         if (value < 0 || value > 2) return set_error(MRT_ERR_INVALID_ARGUMENT, "traversal must be 0, 1 or 2");
         scene->opt_traversal = value;

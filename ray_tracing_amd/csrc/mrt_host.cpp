@@ -514,6 +514,36 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
         auto root = b.build(order, 0);
         emit_full(root.get(), &s.bvh_full);
         emit_device(s, root.get(), &s);
+        // self-contained node records for the wave-synchronous walk
+        s.node_recs.resize(s.node_object.size());
+        for (size_t i = 0; i < s.node_recs.size(); ++i) {
+            DNodeRec& r = s.node_recs[i];
+            std::memset(&r, 0, sizeof(r));
+            for (int a = 0; a < 3; ++a) r.bmin[a] = s.bmin[a][i], r.bmax[a] = s.bmax[a][i];
+            r.object = s.node_object[i];
+            r.skip = s.node_skip[i];
+            r.flags = s.node_flags[i];
+            r.kind = -1;
+            r.simple = 1;
+            if (r.object >= 0) {
+                const DObject& ob = s.objects[(size_t)r.object];
+                const DShape* sh = &s.shapes[(size_t)ob.shape];
+                r.kind = sh->kind;
+                r.identity = ob.identity;
+                r.octree = sh->octree;
+                r.to_object = ob.to_object;
+                if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) {
+                    const DShape* b = &s.shapes[(size_t)sh->boundary];
+                    r.kind2 = b->kind;
+                    std::memcpy(r.p, b->p, sizeof(r.p));
+                    if (b->kind == MRT_SHAPE_MOVING_SPHERE) r.simple = 0;  // needs all ten slots
+                    r.p[9] = -1.0 / sh->p[0];  // ConstantMedium::new, constant_medium.rs:27-32
+                } else {
+                    std::memcpy(r.p, sh->p, sizeof(r.p));
+                }
+                if (r.flags & NODE_DYNAMIC_BOX) r.simple = 0;  // time-dependent boxes use the object tables
+            }
+        }
     }
     return MRT_OK;
 }

@@ -80,6 +80,24 @@ enum : int32_t {
     NODE_TWICE = 2         // span-1 leaf pair folded into one node; evaluate the object twice (bvh.rs:224-232)
 };
 
+// One self-contained record per device BVH node for the wave-synchronous walk: everything the
+// box test and the leaf's intersection test need, so a node costs one batch of scalar loads
+// instead of the chain node -> object -> shape (-> boundary shape).
+struct DNodeRec {
+    double bmin[3], bmax[3];
+    int32_t object;    // >= 0 leaf, -1 inner
+    int32_t skip;
+    int32_t flags;     // NODE_*
+    int32_t kind;      // shape kind of the leaf's object (CONSTANT_MEDIUM for media)
+    int32_t identity;  // object transform is the identity
+    int32_t kind2;     // media: kind of the boundary shape
+    int32_t octree;    // octree index for OCTREE leaves
+    int32_t simple;    // 1: the record is complete (otherwise the walk falls back to the object tables)
+    double p[10];      // shape parameters (media: the boundary's); p[9] = -1/density for media
+    Affine to_object;  // world -> object (used when !identity)
+};
+static_assert(sizeof(DNodeRec) == 256, "DNodeRec must be 256 bytes");
+
 // Host-side flattened scene.
 struct FlatScene {
     std::vector<DObject> objects, lights;
@@ -100,6 +118,7 @@ struct FlatScene {
     // device BVH: duplicate leaves folded; SoA
     std::vector<double> bmin[3], bmax[3];
     std::vector<int32_t> node_object, node_skip, node_flags;
+    std::vector<DNodeRec> node_recs;
     bool has_medium = false;
 };
 
