@@ -22,6 +22,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "mrt_internal.h"
@@ -85,9 +86,18 @@ struct RenderParams {
     uint32_t steps;
 };
 
-// Compile-time scene features: kernels are instantiated per feature set so that scenes without
-// an octree do not carry the voxel walk's registers.
-constexpr int FEAT_OCTREE = 1;
+// Compile-time scene features. The segment kernel is instantiated for a handful of feature sets
+// and a scene runs on the smallest instantiation that covers what it contains, so a scene pays
+// (registers, instruction cache) only for the shapes, materials and backgrounds it uses.
+enum : int {
+    FEAT_OCTREE = 1,    // OctTree shapes (voxel walk)
+    FEAT_SPHERE = 2,    // Sphere / MovingSphere shapes (objects, medium boundaries, lights)
+    FEAT_MEDIUM = 4,    // ConstantMedium shapes
+    FEAT_SPECULAR = 8,  // Metal / Dielectric materials
+    FEAT_TEXTURE = 16,  // textures other than SolidColor
+    FEAT_SKY = 32,      // Sky / SunSky background, or a sun in the sky pdf
+    FEAT_ALL = 63
+};
 
 // ============================================================== small vector math
 struct D3 {
@@ -265,51 +275,23 @@ __device__ __forceinline__ bool box_hit(PP p, const RayD& r, D3 inv, double t_mi
 }
 
 // Deterministic shapes (everything a ConstantMedium may wrap). `sub` = box face.
-template <class PP>
+template <int FEAT, class PP>
 __device__ __forceinline__ bool solid_hit_kp(int kind, PP p, const RayD& r, D3 inv, double t_min, double t_max,
                                              double& t, int& sub) {
     sub = 0;
     switch (kind) {
-        case MRT_SHAPE_SPHERE: return sphere_hit(D3{p[1], p[2], p[3]}, p[0], r, t_min, t_max, t);
-        case MRT_SHAPE_MOVING_SPHERE: return sphere_hit(moving_center(p, r.time), p[0], r, t_min, t_max, t);
+        case MRT_SHAPE_SPHERE:
+            if constexpr ((FEAT & FEAT_SPHERE) != 0) return sphere_hit(D3{p[1], p[2], p[3]}, p[0], r, t_min, t_max, t);
+            return false;
+        case MRT_SHAPE_MOVING_SPHERE:
+            if constexpr ((FEAT & FEAT_SPHERE) != 0) return sphere_hit(moving_center(p, r.time), p[0], r, t_min, t_max, t);
+            return false;
         case MRT_SHAPE_XY_RECT: return rect_hit<2>(p[0], p[1], p[2], p[3], p[4], r, inv, t_min, t_max, t);
         case MRT_SHAPE_XZ_RECT: return rect_hit<1>(p[0], p[1], p[2], p[3], p[4], r, inv, t_min, t_max, t);
         case MRT_SHAPE_YZ_RECT: return rect_hit<0>(p[0], p[1], p[2], p[3], p[4], r, inv, t_min, t_max, t);
         case MRT_SHAPE_RENDER_BOX: return box_hit(p, r, inv, t_min, t_max, t, sub);
         default: return false;
     }
-}
-template <class SP>
-__device__ __forceinline__ bool solid_hit(SP sh, const RayD& r, D3 inv, double t_min, double t_max, double& t,
-                                          int& sub) {
-    return solid_hit_kp(sh->kind, sh->p, r, inv, t_min, t_max, t, sub);
-}
-
-// constant_medium.rs:35-93. One uniform draw at dimension `dim`.
-template <class PP>
-__device__ __forceinline__ bool medium_core(int bkind, PP bp, double neg_inv_density, const RayD& r, D3 inv,
-                                            double t_min, double t_max, const Rng& g, uint32_t dim, double& t_out) {
-    double t1, t2;
-    int s;
-    if (!solid_hit_kp(bkind, bp, r, inv, -10000000000.0, 10000000000.0, t1, s)) return false;
-    if (!solid_hit_kp(bkind, bp, r, inv, t1 + 0.0001, 10000000000.0, t2, s)) return false;
-    if (t1 < t_min) t1 = t_min;
-    if (t2 > t_max) t2 = t_max;
-    if (t1 >= t2) return false;
-    if (t1 < 0.0) t1 = 0.0;
-    double len2 = r.d.x * r.d.x + r.d.y * r.d.y + r.d.z * r.d.z;
-    double ray_length = sqrt(len2);
-    double distance_inside = (t2 - t1) * ray_length;
-    double hit_distance = neg_inv_density * log(rand_scalar(g, 0.0, 1.0, dim));
-    if (hit_distance > distance_inside) return false;
-    t_out = t1 + hit_distance * rcp_fast(ray_length);
-    return true;
-}
-template <class SP>
-__device__ __forceinline__ bool medium_hit(SP shapes, SP sh, const RayD& r, D3 inv, double t_min, double t_max,
-                                           const Rng& g, uint32_t dim, double& t_out) {
-    SP bnd = shapes + sh->boundary;
-    return medium_core(bnd->kind, bnd->p, -1.0 / sh->p[0], r, inv, t_min, t_max, g, dim, t_out);
 }
 
 // Aabb::hit (bvh.rs:18-33): every axis is tested on its own against the ORIGINAL [t_min, t_max].
@@ -525,51 +507,85 @@ __device__ bool octree_hit(const DOctNode* nodes, const DOctree& oc, const RayD&
 // Object::hit (hittable.rs:204-237) without the material: returns t and the sub-shape id.
 // `inv_world` = 1/direction of the world ray; objects with the identity transform use the world
 // ray as it is (the reference's M*(o+d) - M*o differs from d only by rounding).
+// kind/p describe the shape; for a ConstantMedium (constant_medium.rs:35-93) bkind/p describe its
+// boundary, `neg_inv_density` = -1/density, and one uniform is drawn at dimension `medium_dim`.
+// The boundary queries of a medium and the plain query of a solid share ONE copy of the shape
+// code (a loop of one or two rounds), which keeps the kernel's instruction footprint small.
+template <int FEAT, class PP, class AP>
+__device__ __forceinline__ bool leaf_hit(const SceneView& sv, int kind, int bkind, int octree, PP p,
+                                         double neg_inv_density, bool identity, AP to_object, const RayD& ray,
+                                         D3 inv_world, double t_min, double t_max, const Rng& g, uint32_t medium_dim,
+                                         double& t, int& sub, D3& pos) {
+    RayD sr = ray;
+    D3 inv = inv_world;
+    if (!identity) {
+        sr = xform_ray(to_object, false, ray);
+        inv = {rcp_fast(sr.d.x), rcp_fast(sr.d.y), rcp_fast(sr.d.z)};
+    }
+    if constexpr ((FEAT & FEAT_OCTREE) != 0) {
+        if (kind == MRT_SHAPE_OCTREE) return octree_hit(sv.oct_nodes, sv.octrees[octree], sr, inv, t_min, t_max, t, sub, pos);
+    }
+    bool medium = false;
+    if constexpr ((FEAT & FEAT_MEDIUM) != 0) medium = kind == MRT_SHAPE_CONSTANT_MEDIUM;
+    const int k = medium ? bkind : kind;
+    double lo = medium ? -10000000000.0 : t_min;
+    const double hi = medium ? 10000000000.0 : t_max;
+    double t1 = 0.0, t2 = 0.0;
+    int s1 = 0;
+    const int rounds = medium ? 2 : 1;
+#pragma nounroll
+    for (int c = 0; c < rounds; ++c) {
+        double th;
+        int sh;
+        if (!solid_hit_kp<FEAT>(k, p, sr, inv, lo, hi, th, sh)) return false;
+        if (c == 0) t1 = th, s1 = sh, lo = th + 0.0001;
+        else t2 = th;
+    }
+    if (!medium) {
+        t = t1, sub = s1;
+        return true;
+    }
+    if constexpr ((FEAT & FEAT_MEDIUM) != 0) {
+        sub = 0;
+        if (t1 < t_min) t1 = t_min;
+        if (t2 > t_max) t2 = t_max;
+        if (t1 >= t2) return false;
+        if (t1 < 0.0) t1 = 0.0;
+        double len2 = sr.d.x * sr.d.x + sr.d.y * sr.d.y + sr.d.z * sr.d.z;
+        double ray_length = sqrt(len2);
+        double distance_inside = (t2 - t1) * ray_length;
+        double hit_distance = neg_inv_density * log(rand_scalar(g, 0.0, 1.0, medium_dim));
+        if (hit_distance > distance_inside) return false;
+        t = t1 + hit_distance * rcp_fast(ray_length);
+        return true;
+    }
+    return false;
+}
+// Leaf test from the object / shape tables.
 template <int FEAT, class OP, class SP>
 __device__ __forceinline__ bool object_hit(const SceneView& sv, OP ob, SP shapes, const RayD& ray, D3 inv_world,
                                            double t_min, double t_max, const Rng& g, uint32_t medium_dim, double& t,
                                            int& sub, D3& pos) {
-    RayD sr = ray;
-    D3 inv = inv_world;
-    if (!ob->identity) {
-        sr = xform_ray(&ob->to_object, false, ray);
-        inv = {rcp_fast(sr.d.x), rcp_fast(sr.d.y), rcp_fast(sr.d.z)};
-    }
     SP sh = shapes + ob->shape;
-    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) {
-        sub = 0;
-        return medium_hit(shapes, sh, sr, inv, t_min, t_max, g, medium_dim, t);
+    const int kind = sh->kind;
+    auto p = &sh->p[0];
+    int bkind = 0;
+    double nid = 0.0;
+    if constexpr ((FEAT & FEAT_MEDIUM) != 0) {
+        if (kind == MRT_SHAPE_CONSTANT_MEDIUM) {
+            SP b = shapes + sh->boundary;
+            p = &b->p[0], bkind = b->kind, nid = sh->p[9];
+        }
     }
-    if constexpr ((FEAT & FEAT_OCTREE) != 0) {
-        if (sh->kind == MRT_SHAPE_OCTREE)
-            return octree_hit(sv.oct_nodes, sv.octrees[sh->octree], sr, inv, t_min, t_max, t, sub, pos);
-    }
-    return solid_hit(sh, sr, inv, t_min, t_max, t, sub);
+    return leaf_hit<FEAT>(sv, kind, bkind, sh->octree, p, nid, ob->identity != 0, &ob->to_object, ray, inv_world, t_min,
+                          t_max, g, medium_dim, t, sub, pos);
 }
-
-// Leaf test of the wave-synchronous walk from a self-contained node record (scalar operands);
-// records that are not `simple` fall back to the object tables.
+// Leaf test of the wave-synchronous walk from a self-contained node record (scalar operands).
 template <int FEAT, class RP>
 __device__ __forceinline__ bool node_hit(const SceneView& sv, RP r, const RayD& ray, D3 inv_world, double t_min,
                                          double t_max, const Rng& g, uint32_t medium_dim, double& t, int& sub, D3& pos) {
-    if (!r->simple)
-        return object_hit<FEAT>(sv, as_const(sv.objects) + r->object, as_const(sv.shapes), ray, inv_world, t_min, t_max,
-                                g, medium_dim, t, sub, pos);
-    RayD sr = ray;
-    D3 inv = inv_world;
-    if (!r->identity) {
-        sr = xform_ray(&r->to_object, false, ray);
-        inv = {rcp_fast(sr.d.x), rcp_fast(sr.d.y), rcp_fast(sr.d.z)};
-    }
-    const int kind = r->kind;
-    if (kind == MRT_SHAPE_CONSTANT_MEDIUM) {
-        sub = 0;
-        return medium_core(r->kind2, r->p, r->p[9], sr, inv, t_min, t_max, g, medium_dim, t);
-    }
-    if constexpr ((FEAT & FEAT_OCTREE) != 0) {
-        if (kind == MRT_SHAPE_OCTREE) return octree_hit(sv.oct_nodes, sv.octrees[r->octree], sr, inv, t_min, t_max, t, sub, pos);
-    }
-    return solid_hit_kp(kind, r->p, sr, inv, t_min, t_max, t, sub);
+    return leaf_hit<FEAT>(sv, r->kind, r->kind2, r->octree, &r->p[0], r->p[9], r->identity != 0, &r->to_object, ray,
+                          inv_world, t_min, t_max, g, medium_dim, t, sub, pos);
 }
 
 // Leaf box of a MovingSphere-based object for the time window (t0, t1) the reference passes
@@ -600,6 +616,9 @@ struct HitD {
 // pre-order node arrays. Visiting left before right with t_max = left.t and preferring the
 // right result on ties is the same as keeping one running closest t and accepting t <= closest.
 //
+// A span-1 node pair folded into one node (NODE_TWICE) evaluates its object a second time after
+// re-testing the box against the updated bound, with a fresh medium draw (bvh.rs:224-232).
+//
 // Per-lane variant: every lane walks its own node sequence (large trees, incoherent rays).
 template <int FEAT>
 __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng& g, HitD& out) {
@@ -616,28 +635,27 @@ __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng
         const int flags = sv.node_flags[i];
         D3 mn{sv.bmin_x[i], sv.bmin_y[i], sv.bmin_z[i]};
         D3 mx{sv.bmax_x[i], sv.bmax_y[i], sv.bmax_z[i]};
-        if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(sv.objects + obj, sv.shapes, t_min, closest, mn, mx);
+        if constexpr ((FEAT & FEAT_SPHERE) != 0) {
+            if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(sv.objects + obj, sv.shapes, t_min, closest, mn, mx);
+        }
         if (!aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
             i = sv.node_skip[i];
             continue;
         }
         if (obj >= 0) {
             const DObject* ob = sv.objects + obj;
-            const bool is_medium = sv.shapes[ob->shape].kind == MRT_SHAPE_CONSTANT_MEDIUM;
-            double t;
-            int sub;
-            if (object_hit<FEAT>(sv, ob, sv.shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
-                closest = t, best_obj = obj, best_sub = sub;
-            }
-            if (is_medium) medium_ordinal++;
-            if (flags & NODE_TWICE) {
-                // second leaf of a span-1 node: box re-tested against the updated bound, new draw
-                if (aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
-                    if (object_hit<FEAT>(sv, ob, sv.shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
-                        closest = t, best_obj = obj, best_sub = sub;
-                    }
-                    medium_ordinal++;
+            bool is_medium = false;
+            if constexpr ((FEAT & FEAT_MEDIUM) != 0) is_medium = sv.shapes[ob->shape].kind == MRT_SHAPE_CONSTANT_MEDIUM;
+            const int rounds = (flags & NODE_TWICE) ? 2 : 1;
+#pragma nounroll
+            for (int round = 0; round < rounds; ++round) {
+                if (round == 1 && !aabb_hit(mn, mx, ray, inv_d, t_min, closest)) break;
+                double t;
+                int sub;
+                if (object_hit<FEAT>(sv, ob, sv.shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
+                    closest = t, best_obj = obj, best_sub = sub;
                 }
+                if (is_medium) medium_ordinal++;
             }
         }
         i = i + 1;
@@ -650,11 +668,11 @@ __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng
 }
 
 // Wave-synchronous variant for small trees: the whole wave visits the nodes in pre-order with
-// ONE node index, so node, object and shape records are read with scalar loads (SGPR operands,
-// no per-lane scene loads) and the shape-kind switch is a scalar branch. A lane that fails a
-// box test sits out until the walk leaves that subtree (`resume`); a subtree no lane wants is
-// skipped for the whole wave by a ballot. Must be called by every lane of the wave; lanes with
-// live == false only follow along.
+// ONE node index, so a node's record (box, links, the leaf's shape parameters and transform)
+// is read with scalar loads (SGPR operands, no per-lane scene loads) and the shape-kind switch
+// is a scalar branch. A lane that fails a box test sits out until the walk leaves that subtree
+// (`resume`); a subtree no lane wants is skipped for the whole wave by a ballot. Must be called
+// by every lane of the wave; lanes with live == false only follow along.
 template <int FEAT>
 __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng& g, bool live, HitD& out) {
     const double t_min = (double)0.001f;
@@ -676,8 +694,10 @@ __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng
         D3 mx{r->bmax[0], r->bmax[1], r->bmax[2]};
         bool pass = false;
         if (i >= resume) {
-            if (flags & NODE_DYNAMIC_BOX)
-                dynamic_leaf_box(as_const(sv.objects) + obj, as_const(sv.shapes), t_min, closest, mn, mx);
+            if constexpr ((FEAT & FEAT_SPHERE) != 0) {
+                if (flags & NODE_DYNAMIC_BOX)
+                    dynamic_leaf_box(as_const(sv.objects) + obj, as_const(sv.shapes), t_min, closest, mn, mx);
+            }
             pass = aabb_hit(mn, mx, ray, inv_d, t_min, closest);
             if (!pass) resume = skip;
         }
@@ -685,20 +705,20 @@ __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng
             i = skip;
             continue;
         }
-        if (obj >= 0 && pass) {
-            const bool is_medium = r->kind == MRT_SHAPE_CONSTANT_MEDIUM;
-            double t;
-            int sub;
-            if (node_hit<FEAT>(sv, r, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
-                closest = t, best_obj = obj, best_sub = sub;
-            }
-            if (is_medium) medium_ordinal++;
-            if (flags & NODE_TWICE) {
-                if (aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
+        if (obj >= 0) {
+            bool is_medium = false;
+            if constexpr ((FEAT & FEAT_MEDIUM) != 0) is_medium = r->kind == MRT_SHAPE_CONSTANT_MEDIUM;
+            const int rounds = (flags & NODE_TWICE) ? 2 : 1;
+#pragma nounroll
+            for (int round = 0; round < rounds; ++round) {
+                if (round == 1) pass = pass && aabb_hit(mn, mx, ray, inv_d, t_min, closest);
+                if (pass) {
+                    double t;
+                    int sub;
                     if (node_hit<FEAT>(sv, r, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
                         closest = t, best_obj = obj, best_sub = sub;
                     }
-                    medium_ordinal++;
+                    if (is_medium) medium_ordinal++;
                 }
             }
         }
@@ -740,13 +760,15 @@ __device__ __forceinline__ void rect_uv(double a0, double a1, double b0, double 
     v = (b - b0) / (b1 - b0);
 }
 // Texture coordinates of the hit; evaluated only for textures that read them.
-template <class SP>
+template <int FEAT, class SP>
 __device__ void surface_uv(SP sh, const Surface& s, double& u, double& v) {
     auto p = sh->p;
     u = 0.0, v = 0.0;
     switch (sh->kind) {
         case MRT_SHAPE_SPHERE:
-        case MRT_SHAPE_MOVING_SPHERE: sphere_uv(s.n_obj, u, v); break;
+        case MRT_SHAPE_MOVING_SPHERE:
+            if constexpr ((FEAT & FEAT_SPHERE) != 0) sphere_uv(s.n_obj, u, v);
+            break;
         case MRT_SHAPE_XY_RECT: rect_uv<2>(p[0], p[1], p[2], p[3], s, u, v); break;
         case MRT_SHAPE_XZ_RECT: rect_uv<1>(p[0], p[1], p[2], p[3], s, u, v); break;
         case MRT_SHAPE_YZ_RECT: rect_uv<0>(p[0], p[1], p[2], p[3], s, u, v); break;
@@ -770,9 +792,14 @@ __device__ void surface_at(OP ob, SP shapes, const RayD& ray, double t, int sub,
     s.time = sr.time;
     s.material = sh->material;
     s.sub = sub;
+    s.n_obj = {1.0, 0.0, 0.0};
     switch (sh->kind) {
-        case MRT_SHAPE_SPHERE: s.n_obj = (s.pos_obj - D3{p[1], p[2], p[3]}) * rcp_fast(p[0]); break;
-        case MRT_SHAPE_MOVING_SPHERE: s.n_obj = (s.pos_obj - moving_center(p, sr.time)) * rcp_fast(p[0]); break;
+        case MRT_SHAPE_SPHERE:
+            if constexpr ((FEAT & FEAT_SPHERE) != 0) s.n_obj = (s.pos_obj - D3{p[1], p[2], p[3]}) * rcp_fast(p[0]);
+            break;
+        case MRT_SHAPE_MOVING_SPHERE:
+            if constexpr ((FEAT & FEAT_SPHERE) != 0) s.n_obj = (s.pos_obj - moving_center(p, sr.time)) * rcp_fast(p[0]);
+            break;
         case MRT_SHAPE_XY_RECT: s.n_obj = {0.0, 0.0, p[5]}; break;
         case MRT_SHAPE_XZ_RECT: s.n_obj = {0.0, p[5], 0.0}; break;
         case MRT_SHAPE_YZ_RECT: s.n_obj = {p[5], 0.0, 0.0}; break;
@@ -790,9 +817,7 @@ __device__ void surface_at(OP ob, SP shapes, const RayD& ray, double t, int sub,
             s.material = -1 - sub / 6;  // voxel record index, negative = VoxelMaterial::Lambertian
             break;
         }
-        default:  // ConstantMedium: normal (1,0,0), front_face true for the phase function
-            s.n_obj = {1.0, 0.0, 0.0};
-            break;
+        default: break;  // ConstantMedium: normal (1,0,0), front_face true for the phase function
     }
     s.front_face = sh->kind == MRT_SHAPE_CONSTANT_MEDIUM ? true : (dot(sr.d, s.n_obj) <= 0.0);
 }
@@ -816,7 +841,12 @@ __device__ __forceinline__ uint32_t f64_as_index(double v, uint32_t hi) {  // Ru
     if (v >= (double)hi) return hi;
     return (uint32_t)v;
 }
+template <int FEAT>
 __device__ F3 texture_color(const SceneView& sv, int tex, const DShape* sh, const Surface& sf) {
+    if constexpr ((FEAT & FEAT_TEXTURE) == 0) {  // every texture of the scene is a SolidColor
+        const DTexture& t = sv.textures[tex];
+        return {t.color[0], t.color[1], t.color[2]};
+    }
     F3 acc{1.f, 1.f, 1.f};
     const D3 pos = sf.pos_obj;
     double u = 0.0, v = 0.0;
@@ -831,7 +861,7 @@ __device__ F3 texture_color(const SceneView& sv, int tex, const DShape* sh, cons
         switch (t.kind) {
             case MRT_TEX_SOLID: c = {t.color[0], t.color[1], t.color[2]}; break;
             case MRT_TEX_IMAGE: {  // parallel_image.rs:66-71
-                if (!have_uv) surface_uv(sh, sf, u, v), have_uv = true;
+                if (!have_uv) surface_uv<FEAT>(sh, sf, u, v), have_uv = true;
                 const DImage& im = sv.images[t.image];
                 uint32_t x = f64_as_index(u * ((double)im.width - 1.0), (uint32_t)im.width - 1);
                 double vv = 1.0 - v;
@@ -841,7 +871,7 @@ __device__ F3 texture_color(const SceneView& sv, int tex, const DShape* sh, cons
                 break;
             }
             case MRT_TEX_DEBUG_V:  // texture.rs:231-238
-                if (!have_uv) surface_uv(sh, sf, u, v), have_uv = true;
+                if (!have_uv) surface_uv<FEAT>(sh, sf, u, v), have_uv = true;
                 c = (v != v) ? F3{0.f, 0.f, 0.f} : F3{(float)v, (float)v, (float)v};
                 break;
             case MRT_TEX_MULTIPLY:  // texture.rs:29-31
@@ -881,15 +911,20 @@ __device__ __forceinline__ double rect_prob(double a0, double a1, double b0, dou
     double area = (a1 - a0) * (b1 - b0);
     return dot(to_light, to_light) * rcp_fast(cos_alpha * area);
 }
-template <class SP>
+template <int FEAT, class SP>
 __device__ double shape_prob(SP shapes, SP sh, const RayD& r) {
-    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = shapes + sh->boundary;  // constant_medium.rs:98-100
+    if constexpr ((FEAT & FEAT_MEDIUM) != 0) {
+        if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = shapes + sh->boundary;  // constant_medium.rs:98-100
+    }
     auto p = sh->p;
     switch (sh->kind) {
         case MRT_SHAPE_SPHERE: {
-            double area = M_PI * (p[0] * p[0]);
-            D3 to_light = D3{p[1], p[2], p[3]} - r.o;
-            return dot(to_light, to_light) / area;
+            if constexpr ((FEAT & FEAT_SPHERE) != 0) {
+                double area = M_PI * (p[0] * p[0]);
+                D3 to_light = D3{p[1], p[2], p[3]} - r.o;
+                return dot(to_light, to_light) / area;
+            }
+            return 0.0;
         }
         case MRT_SHAPE_XY_RECT: return rect_prob<2>(p[0], p[1], p[2], p[3], p[4], r.o);
         case MRT_SHAPE_XZ_RECT: return rect_prob<1>(p[0], p[1], p[2], p[3], p[4], r.o);
@@ -925,19 +960,23 @@ __device__ __forceinline__ void rect_generate(double a0, double a1, double b0, d
     o.direction = end_point - origin;
     o.end_point = end_point;
 }
-template <class SP>
+template <int FEAT, class SP>
 __device__ void shape_generate(SP shapes, SP sh, D3 origin, double time, const Rng& g, AreaInfo& o) {
-    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = shapes + sh->boundary;  // constant_medium.rs:101-103
+    if constexpr ((FEAT & FEAT_MEDIUM) != 0) {
+        if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = shapes + sh->boundary;  // constant_medium.rs:101-103
+    }
     auto p = sh->p;
     switch (sh->kind) {
         case MRT_SHAPE_SPHERE: {  // sphere.rs:72-87
-            D3 sd = rand_unit_vec(g, MRT_DIM_LIGHT_SPHERE);
-            D3 end_point = D3{p[1], p[2], p[3]} + p[0] * sd;
-            o.to_area = {origin, normalize(end_point - origin), time};
-            o.normal = sd;
-            o.area = M_PI * (p[0] * p[0]);
-            o.direction = end_point - origin;
-            o.end_point = end_point;
+            if constexpr ((FEAT & FEAT_SPHERE) != 0) {
+                D3 sd = rand_unit_vec(g, MRT_DIM_LIGHT_SPHERE);
+                D3 end_point = D3{p[1], p[2], p[3]} + p[0] * sd;
+                o.to_area = {origin, normalize(end_point - origin), time};
+                o.normal = sd;
+                o.area = M_PI * (p[0] * p[0]);
+                o.direction = end_point - origin;
+                o.end_point = end_point;
+            }
             break;
         }
         case MRT_SHAPE_XY_RECT: rect_generate<2>(p[0], p[1], p[2], p[3], p[4], p[5], origin, time, g, o); break;
@@ -962,11 +1001,11 @@ __device__ void shape_generate(SP shapes, SP sh, D3 origin, double time, const R
     }
 }
 // Object::generate_ray_in_area, hittable.rs:289-312
-template <class OP, class SP>
+template <int FEAT, class OP, class SP>
 __device__ void object_generate(OP ob, SP shapes, D3 origin, double time, const Rng& g, AreaInfo& out) {
     SP sh = shapes + ob->shape;
     if (ob->identity) {
-        shape_generate(shapes, sh, origin, time, g, out);
+        shape_generate<FEAT>(shapes, sh, origin, time, g, out);
         // the reference still routes every vector through the (identity) inverse
         D3 o = out.to_area.o;
         out.to_area.d = (o + out.to_area.d) - o;
@@ -975,7 +1014,7 @@ __device__ void object_generate(OP ob, SP shapes, D3 origin, double time, const 
         return;
     }
     AreaInfo a;
-    shape_generate(shapes, sh, apply(&ob->to_object, origin), time, g, a);
+    shape_generate<FEAT>(shapes, sh, apply(&ob->to_object, origin), time, g, a);
     auto inv = &ob->to_world;
     out.end_point = apply(inv, a.end_point);
     out.to_area = xform_ray(inv, false, a.to_area);
@@ -986,8 +1025,10 @@ __device__ void object_generate(OP ob, SP shapes, D3 origin, double time, const 
 }
 
 // LightPdf::value, pdf.rs:82-99 with World::nearest_light_hit, world.rs:98-110. Returns false for None.
+template <int FEAT>
 __device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng& g, uint32_t& light_queries,
                                 double& value) {
+    constexpr int LF = FEAT & ~FEAT_OCTREE;  // an octree is never a light
     light_queries++;
     bool any = false;
     double best_t = 0.0;
@@ -1001,8 +1042,10 @@ __device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng&
         double t;
         int sub;
         D3 unused_pos;
-        bool h = object_hit<0>(sv, lob, cshapes, ray, inv_d, ray.time, DBL_MAX, g, MRT_DIM_LIGHT_QUERY_MEDIUM + ordinal, t, sub, unused_pos);
-        if (cshapes[lob->shape].kind == MRT_SHAPE_CONSTANT_MEDIUM) ordinal++;
+        bool h = object_hit<LF>(sv, lob, cshapes, ray, inv_d, ray.time, DBL_MAX, g, MRT_DIM_LIGHT_QUERY_MEDIUM + ordinal, t, sub, unused_pos);
+        if constexpr ((LF & FEAT_MEDIUM) != 0) {
+            if (cshapes[lob->shape].kind == MRT_SHAPE_CONSTANT_MEDIUM) ordinal++;
+        }
         if (!h) continue;
         if (!any || !(best_t < t)) {  // reduce(|acc, x| if acc.t < x.t { acc } else { x })
             any = true, best_t = t, best = i, best_sub = sub;
@@ -1011,7 +1054,7 @@ __device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng&
     if (!any) return false;
     const DObject* ob = sv.lights + best;
     Surface s;
-    surface_at<0>(ob, sv.shapes, ray, best_t, best_sub, D3{0.0, 0.0, 0.0}, s);
+    surface_at<LF>(ob, sv.shapes, ray, best_t, best_sub, D3{0.0, 0.0, 0.0}, s);
     D3 hit_pos = point_to_world(ob, s.pos_obj);
     D3 hit_n = normal_to_world(ob, s.n_obj);
     D3 to_light = hit_pos - ray.o;
@@ -1020,7 +1063,7 @@ __device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng&
         // Object::prob applies the INVERSE transform to the ray (hittable.rs:284-287)
         RayD pr{ray.o, normalize(to_light), best_t};
         RayD tr = xform_ray(&ob->to_world, ob->identity != 0, pr);
-        value = shape_prob(sv.shapes, sv.shapes + ob->shape, tr);
+        value = shape_prob<LF>(sv.shapes, sv.shapes + ob->shape, tr);
     } else {
         value = 0.0;
     }
@@ -1044,6 +1087,7 @@ __device__ __forceinline__ D3 sun_direction(const mrt_sun& s) {  // sun.rs:17-20
 }
 
 // LambertianPDF::generate, pdf.rs:234-282. Returns false for None.
+template <int FEAT>
 __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double incoming_time, D3 hit_point,
                                     const Rng& g, uint32_t& light_queries, D3& out_dir, double& out_value) {
     Onb uvw = onb_from_w(pdf_normal);
@@ -1065,7 +1109,7 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
         if (sv.n_lights == 0) return false;
         uint32_t idx = rand_u32(g, 0, (uint32_t)sv.n_lights, MRT_DIM_LIGHT_INDEX);
         AreaInfo ai;
-        object_generate(sv.lights + idx, sv.shapes, hit_point, incoming_time, g, ai);
+        object_generate<(FEAT & ~FEAT_OCTREE)>(sv.lights + idx, sv.shapes, hit_point, incoming_time, g, ai);
         D3 nd = normalize(ai.to_area.d);
         double light_cos = fabs(dot(nd, ai.normal));
         double dist_squared = dot(ai.direction, ai.direction);
@@ -1073,10 +1117,12 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
         own = dist_squared * rcp_fast(light_cos * ai.area);
         dir = nd;
     } else {  // SkyPdf::generate, pdf.rs:154-193
-        if (!sv.sun.has_sun) {
+        bool has_sun = false;
+        if constexpr ((FEAT & FEAT_SKY) != 0) has_sun = sv.sun.has_sun != 0;
+        if (!has_sun) {
             dir = rand_unit_vec(g, MRT_DIM_SKY);
             own = 4.0 * M_PI;
-        } else {
+        } else if constexpr ((FEAT & FEAT_SKY) != 0) {
             double rr = sqrt(rand_scalar(g, 0.0, 1.0, MRT_DIM_SUN_R));
             double theta = rand_scalar(g, 0.0, 2.0 * M_PI, MRT_DIM_SUN_THETA);
             rr = rr * sv.sun.radius;
@@ -1092,7 +1138,7 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
     int total = 0;
     if (r != 1) {  // light_pdf.value
         double lv;
-        if (light_pdf_value(sv, value_ray, g, light_queries, lv)) sum += lv, total++;
+        if (light_pdf_value<FEAT>(sv, value_ray, g, light_queries, lv)) sum += lv, total++;
     }
     if (r != 0) {  // sin_pdf.value, pdf.rs:32-39 (direction NOT normalised here)
         double c = dot(dir, uvw.w);
@@ -1101,7 +1147,9 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
     }
     if (r != 2) {  // sky_pdf.value, pdf.rs:135-148
         double svl = 1.0;
-        if (sv.sun.has_sun) svl = dot(dir, sun_direction(sv.sun)) >= cos(sv.sun.radius) ? 1.0 : 0.0;
+        if constexpr ((FEAT & FEAT_SKY) != 0) {
+            if (sv.sun.has_sun) svl = dot(dir, sun_direction(sv.sun)) >= cos(sv.sun.radius) ? 1.0 : 0.0;
+        }
         sum += svl;
         total++;
     }
@@ -1119,9 +1167,10 @@ __device__ __forceinline__ F3 sky_color(double intensity, const RayD& ray) {  //
     F3 c{1.0f * a + 0.5f * b, 1.0f * a + 0.7f * b, 1.0f * a + 1.0f * b};
     return {c.r * k, c.g * k, c.b * k};
 }
+template <int FEAT>
 __device__ F3 background_color(const SceneView& sv, const RayD& ray) {
     const mrt_background& b = sv.bg;
-    if (b.kind == MRT_BG_CONSTANT) return {b.color[0], b.color[1], b.color[2]};  // constant_color.rs:12-14
+    if ((FEAT & FEAT_SKY) == 0 || b.kind == MRT_BG_CONSTANT) return {b.color[0], b.color[1], b.color[2]};  // constant_color.rs:12-14
     if (b.kind == MRT_BG_SUN_SKY) {  // sun_sky.rs:32-60
         double r = cos(b.sun_phi);
         D3 sun_ray{r * cos(b.sun_theta), sin(b.sun_phi), r * sin(b.sun_theta)};
@@ -1141,7 +1190,9 @@ __device__ RayD camera_ray(const SceneView& sv, uint32_t x, uint32_t y, uint32_t
     double s = ((double)x + rand_scalar(g, 0.0, 1.0, MRT_DIM_JITTER_U)) / ((double)width - 1.0);
     double t = ((double)y + rand_scalar(g, 0.0, 1.0, MRT_DIM_JITTER_V)) / ((double)height - 1.0);
     D3 p{0.0, 0.0, 0.0};
-    for (uint32_t k = 0; k < MRT_MAX_REJECT; ++k) {
+    // rand_in_unit_disk (camera.rs:91); with a zero lens radius the sample is multiplied by 0 and
+    // the draws are addressed by dimension, so skipping them changes nothing else
+    for (uint32_t k = 0; c.lens_radius != 0.0 && k < MRT_MAX_REJECT; ++k) {
         D3 q{rand_scalar(g, -1.0, 1.0, MRT_DIM_LENS + 2 * k), rand_scalar(g, -1.0, 1.0, MRT_DIM_LENS + 2 * k + 1), 0.0};
         if (dot(q, q) < 1.0) {
             p = q;
@@ -1171,7 +1222,7 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
                             F3& radiance, uint32_t& light_queries) {
     radiance = {0.f, 0.f, 0.f};
     if (!hit) {
-        F3 bg = background_color(sv, ray);
+        F3 bg = background_color<FEAT>(sv, ray);
         radiance = thr * bg;
         return false;
     }
@@ -1182,25 +1233,28 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
     const bool voxel_mat = (FEAT & FEAT_OCTREE) != 0 && s.material < 0;
     const DMaterial& m = sv.materials[voxel_mat ? 0 : s.material];
     const int mkind = voxel_mat ? (int)MRT_MAT_LAMBERTIAN : m.kind;
+    // Texture value of the material (emitted colour / albedo); evaluated once for every material kind.
+    F3 att{m.color[0], m.color[1], m.color[2]};
+    if (voxel_mat) {
+        if constexpr ((FEAT & FEAT_OCTREE) != 0) {
+            const mrt_voxel& vx = sv.oct_voxels[-1 - s.material];
+            att = {vx.albedo[0], vx.albedo[1], vx.albedo[2]};
+        }
+    } else if (mkind != MRT_MAT_DIELECTRIC) {
+        att = texture_color<FEAT>(sv, m.texture, sv.shapes + ob->shape, s);
+    }
     // HitRecord::new (hittable.rs:414-448): emit first, else scatter, else nothing.
     switch (mkind) {
         case MRT_MAT_DIFFUSE_LIGHT: {  // material.rs:236-248
-            if (s.front_face) radiance = thr * texture_color(sv, m.texture, sv.shapes + ob->shape, s);
+            if (s.front_face) radiance = thr * att;
             return false;
         }
         case MRT_MAT_LAMBERTIAN: {  // material.rs:54-64 + ray_tracer.rs:230-268
-            F3 att;
-            if (voxel_mat) {
-                const mrt_voxel& vx = sv.oct_voxels[-1 - s.material];
-                att = {vx.albedo[0], vx.albedo[1], vx.albedo[2]};
-            } else {
-                att = texture_color(sv, m.texture, sv.shapes + ob->shape, s);
-            }
             D3 pos_w = point_to_world(ob, s.pos_obj);
             D3 n_w = normal_to_world(ob, s.n_obj);
             D3 dir;
             double value;
-            if (!lambertian_generate(sv, s.n_obj, ray.time, pos_w, g, light_queries, dir, value)) return false;
+            if (!lambertian_generate<FEAT>(sv, s.n_obj, ray.time, pos_w, g, light_queries, dir, value)) return false;
             double cosine = dot(n_w, normalize(dir));  // Lambertian::scattering_pdf_fn, material.rs:30-41
             if (cosine < 0.0) return false;
             double scattering_pdf = cosine * INV_PI;
@@ -1211,38 +1265,42 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
             break;
         }
         case MRT_MAT_METAL: {  // material.rs:105-124; the specular ray stays in OBJECT space
-            D3 reflected = reflect(normalize(s.dir_obj), s.n_obj);
-            if (!(dot(reflected, s.n_obj) > 0.0)) return false;
-            F3 att = texture_color(sv, m.texture, sv.shapes + ob->shape, s);
-            thr = thr * att;
-            ray = {s.pos_obj, reflected + m.fuzz * rand_unit_vec(g, MRT_DIM_METAL_FUZZ), s.time};
-            break;
+            if constexpr ((FEAT & FEAT_SPECULAR) != 0) {
+                D3 reflected = reflect(normalize(s.dir_obj), s.n_obj);
+                if (!(dot(reflected, s.n_obj) > 0.0)) return false;
+                thr = thr * att;
+                ray = {s.pos_obj, reflected + m.fuzz * rand_unit_vec(g, MRT_DIM_METAL_FUZZ), s.time};
+                break;
+            }
+            return false;
         }
         case MRT_MAT_DIELECTRIC: {  // material.rs:141-196
-            double ratio = s.front_face ? 1.0 / m.index_refraction : m.index_refraction;
-            D3 unit = normalize(s.dir_obj);
-            double cos_theta = fmin(dot(s.n_obj, -1.0 * unit), 1.0);
-            double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
-            bool can_not_refract = (ratio * sin_theta) > 1.0;
-            double r0 = (1.0 - ratio) / (1.0 + ratio);
-            r0 = r0 * r0;
-            double om = 1.0 - cos_theta;
-            double refl = r0 + (1.0 - r0) * (om * om * om * om * om);
-            D3 dir;
-            if (can_not_refract || refl > rng_f64(g, MRT_DIM_DIELECTRIC)) {
-                dir = reflect(unit, s.n_obj);
-            } else {
-                double ct = fmin(dot(s.n_obj, -1.0 * unit), 1.0);
-                D3 perp = ratio * (unit + ct * s.n_obj);
-                D3 par = -1.0 * s.n_obj * sqrt(fabs(1.0 - dot(perp, perp)));
-                dir = perp + par;
+            if constexpr ((FEAT & FEAT_SPECULAR) != 0) {
+                double ratio = s.front_face ? 1.0 / m.index_refraction : m.index_refraction;
+                D3 unit = normalize(s.dir_obj);
+                double cos_theta = fmin(dot(s.n_obj, -1.0 * unit), 1.0);
+                double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
+                bool can_not_refract = (ratio * sin_theta) > 1.0;
+                double r0 = (1.0 - ratio) / (1.0 + ratio);
+                r0 = r0 * r0;
+                double om = 1.0 - cos_theta;
+                double refl = r0 + (1.0 - r0) * (om * om * om * om * om);
+                D3 dir;
+                if (can_not_refract || refl > rng_f64(g, MRT_DIM_DIELECTRIC)) {
+                    dir = reflect(unit, s.n_obj);
+                } else {
+                    double ct = fmin(dot(s.n_obj, -1.0 * unit), 1.0);
+                    D3 perp = ratio * (unit + ct * s.n_obj);
+                    D3 par = -1.0 * s.n_obj * sqrt(fabs(1.0 - dot(perp, perp)));
+                    dir = perp + par;
+                }
+                thr = thr * att;
+                ray = {s.pos_obj, dir, s.time};
+                break;
             }
-            thr = thr * F3{m.color[0], m.color[1], m.color[2]};
-            ray = {s.pos_obj, dir, s.time};
-            break;
+            return false;
         }
         default: {  // MRT_MAT_ISOTROPIC, material.rs:274-285
-            F3 att = texture_color(sv, m.texture, sv.shapes + ob->shape, s);
             thr = thr * att;
             ray = {s.pos_obj, rand_unit_vec(g, MRT_DIM_ISOTROPIC), s.time};
             break;
@@ -1270,31 +1328,6 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
     rays++;
     return shade_stage<FEAT>(sv, ray, thr, g, h, hit, radiance, light_queries);
 }
-
-// Shading class of a lane after the nearest-hit query; lanes of one class run the same code.
-enum : int { CLS_LAMB_COS = 0, CLS_LAMB_LIGHT = 1, CLS_LAMB_SKY = 2, CLS_SPECULAR = 3, CLS_TERMINAL = 4, CLS_DEAD = 5, N_CLS = 6 };
-template <int FEAT>
-__device__ __forceinline__ int shading_class(const SceneView& sv, const Rng& g, const HitD& h, bool live, bool hit) {
-    if (!live) return CLS_DEAD;
-    if (!hit) return CLS_TERMINAL;
-    const DShape& sh = sv.shapes[sv.objects[h.obj].shape];
-    int kind = MRT_MAT_LAMBERTIAN;
-    if (!((FEAT & FEAT_OCTREE) != 0 && sh.kind == MRT_SHAPE_OCTREE)) kind = sv.materials[sh.material].kind;
-    if (kind == MRT_MAT_LAMBERTIAN) return (int)rand_u32(g, 0, 3, MRT_DIM_PDF_CHOICE);  // pdf.rs:240
-    if (kind == MRT_MAT_DIFFUSE_LIGHT) return CLS_TERMINAL;
-    return CLS_SPECULAR;
-}
-
-// LDS image for the workgroup-local sort of path states (one slot per thread).
-template <int FEAT>
-struct SortLds {
-    static constexpr int ND = (FEAT & FEAT_OCTREE) ? 11 : 8;
-    double d[ND][256];     // ray origin, direction, time, hit t (+ octree hit position)
-    uint64_t key[256];
-    float f[3][256];       // throughput
-    uint32_t u[4][256];    // pixel, seg, obj, sub
-    uint32_t cnt[4][8];    // per wave, per class
-};
 
 // ============================================================== kernels
 constexpr int BLOCK = 256;
@@ -1394,146 +1427,6 @@ __global__ void __launch_bounds__(BLOCK, SEG_WAVES_PER_SIMD) k_segments(SceneVie
     light_queries = wave_sum(light_queries);
     if (lane_id() == 0) {
         if (live) atomicAdd(&ctr->live, live);
-        if (rays) atomicAdd(&ctr->rays, (unsigned long long)rays);
-        if (light_queries) atomicAdd(&ctr->light_queries, (unsigned long long)light_queries);
-    }
-}
-
-// Variant of k_segments with a workgroup-local sort: after the nearest-hit query the 256 path
-// states of the workgroup are redistributed through LDS by shading class (counting sort: wave
-// ballots + popcounts, per-wave counts in LDS), so each wave shades (mostly) one class and dead
-// lanes gather in the last waves. Slots are anonymous, so states never move back.
-// Requires n_slots to be a multiple of the workgroup size.
-template <bool WAVE, int FEAT>
-__global__ void __launch_bounds__(BLOCK, SEG_WAVES_PER_SIMD) k_segments_sorted(SceneView sv, Pool pool, RenderParams rp,
-                                                                            Counters* ctr) {
-    __shared__ SortLds<FEAT> lds;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t slot = blockIdx.x * BLOCK + tid;
-    const uint32_t wave = tid >> 6;
-    int32_t seg = pool.seg[slot];
-    RayD ray{{0, 0, 0}, {0, 0, 1}, 0};
-    F3 thr{0.f, 0.f, 0.f};
-    uint32_t pixel = 0;
-    uint64_t key = 0;
-    if (seg >= 0) {
-        ray.o = {pool.ox[slot], pool.oy[slot], pool.oz[slot]};
-        ray.d = {pool.dx[slot], pool.dy[slot], pool.dz[slot]};
-        ray.time = pool.tm[slot];
-        thr = {pool.tr[slot], pool.tg[slot], pool.tb[slot]};
-        pixel = pool.pixel[slot];
-        key = pool.key[slot];
-    }
-    uint32_t rays = 0, light_queries = 0;
-    bool exhausted = false;
-    for (uint32_t step = 0; step < rp.steps; ++step) {
-        // ---- regeneration (as in k_segments)
-        bool want = seg < 0 && !exhausted;
-        unsigned long long mask = __ballot(want);
-        if (mask) {
-            uint32_t n_want = (uint32_t)__popcll(mask);
-            unsigned long long base = 0;
-            int leader = __ffsll((long long)mask) - 1;
-            if ((int)lane_id() == leader) base = atomicAdd(&ctr->work_next, (unsigned long long)n_want);
-            base = __shfl(base, leader, 64);
-            if (want) {
-                unsigned long long w = base + (unsigned long long)__popcll(mask & ((1ULL << lane_id()) - 1ULL));
-                if (w < rp.n_work) {
-                    unsigned long long sample = w / rp.npix_strip;
-                    uint32_t pl = (uint32_t)(w - sample * rp.npix_strip);
-                    uint32_t y = pl / rp.strip_w;
-                    uint32_t x = rp.x0 + (pl - y * rp.strip_w);
-                    pixel = x + y * rp.width;
-                    key = path_key(rp.seed, (uint64_t)pixel, rp.first_sample + sample);
-                    Rng g0{key, 0};
-                    ray = camera_ray(sv, x, y, rp.width, rp.height, g0);
-                    thr = {1.f, 1.f, 1.f};
-                    seg = 0;
-                } else {
-                    exhausted = true;
-                }
-            }
-        }
-        bool live = seg >= 0;
-        if (!__syncthreads_or(live ? 1 : 0)) break;  // block-uniform exit; also fences the LDS image
-
-        // ---- nearest hit
-        Rng g{key, (uint32_t)(live ? seg : 0)};
-        HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
-        bool hit;
-        if (WAVE) hit = nearest_hit_wave<FEAT>(sv, ray, g, live, h);
-        else hit = live && nearest_hit_lane<FEAT>(sv, ray, g, h);
-        if (live) rays++;
-
-        // ---- counting sort by shading class
-        const int cls = shading_class<FEAT>(sv, g, h, live, hit);
-        uint32_t rank = 0;
-        unsigned long long my_mask = 0;
-#pragma unroll
-        for (int c = 0; c < N_CLS; ++c) {
-            unsigned long long m = __ballot(cls == c);
-            if (lane_id() == 0) lds.cnt[wave][c] = (uint32_t)__popcll(m);
-            if (cls == c) my_mask = m;
-        }
-        rank = (uint32_t)__popcll(my_mask & ((1ULL << lane_id()) - 1ULL));
-        __syncthreads();
-        uint32_t dst = rank;
-#pragma unroll
-        for (int c = 0; c < N_CLS; ++c) {
-#pragma unroll
-            for (int w = 0; w < BLOCK / 64; ++w) {
-                uint32_t n = lds.cnt[w][c];
-                if (c < cls || (c == cls && (uint32_t)w < wave)) dst += n;
-            }
-        }
-        lds.d[0][dst] = ray.o.x, lds.d[1][dst] = ray.o.y, lds.d[2][dst] = ray.o.z;
-        lds.d[3][dst] = ray.d.x, lds.d[4][dst] = ray.d.y, lds.d[5][dst] = ray.d.z;
-        lds.d[6][dst] = ray.time, lds.d[7][dst] = h.t;
-        if constexpr ((FEAT & FEAT_OCTREE) != 0) lds.d[8][dst] = h.pos.x, lds.d[9][dst] = h.pos.y, lds.d[10][dst] = h.pos.z;
-        lds.key[dst] = key;
-        lds.f[0][dst] = thr.r, lds.f[1][dst] = thr.g, lds.f[2][dst] = thr.b;
-        lds.u[0][dst] = pixel, lds.u[1][dst] = (uint32_t)seg, lds.u[2][dst] = (uint32_t)(hit ? h.obj : -1), lds.u[3][dst] = (uint32_t)h.sub;
-        __syncthreads();
-        ray.o = {lds.d[0][tid], lds.d[1][tid], lds.d[2][tid]};
-        ray.d = {lds.d[3][tid], lds.d[4][tid], lds.d[5][tid]};
-        ray.time = lds.d[6][tid], h.t = lds.d[7][tid];
-        if constexpr ((FEAT & FEAT_OCTREE) != 0) h.pos = {lds.d[8][tid], lds.d[9][tid], lds.d[10][tid]};
-        key = lds.key[tid];
-        thr = {lds.f[0][tid], lds.f[1][tid], lds.f[2][tid]};
-        pixel = lds.u[0][tid], seg = (int32_t)lds.u[1][tid], h.obj = (int32_t)lds.u[2][tid], h.sub = (int32_t)lds.u[3][tid];
-        live = seg >= 0;
-        hit = h.obj >= 0;
-
-        // ---- material response
-        if (live) {
-            Rng g2{key, (uint32_t)seg};
-            F3 radiance;
-            bool cont = shade_stage<FEAT>(sv, ray, thr, g2, h, hit, radiance, light_queries);
-            seg++;
-            if (cont && seg >= 50) cont = false;
-            if (!cont) {
-                float* px = rp.accum + (size_t)pixel * 3;
-                if (radiance.r != 0.f) atomicAdd(px + 0, radiance.r);
-                if (radiance.g != 0.f) atomicAdd(px + 1, radiance.g);
-                if (radiance.b != 0.f) atomicAdd(px + 2, radiance.b);
-                seg = -1;
-            }
-        }
-    }
-    pool.seg[slot] = seg;
-    if (seg >= 0) {
-        pool.ox[slot] = ray.o.x, pool.oy[slot] = ray.o.y, pool.oz[slot] = ray.o.z;
-        pool.dx[slot] = ray.d.x, pool.dy[slot] = ray.d.y, pool.dz[slot] = ray.d.z;
-        pool.tm[slot] = ray.time;
-        pool.tr[slot] = thr.r, pool.tg[slot] = thr.g, pool.tb[slot] = thr.b;
-        pool.pixel[slot] = pixel;
-        pool.key[slot] = key;
-    }
-    uint32_t live_n = wave_sum(seg >= 0 ? 1u : 0u);
-    rays = wave_sum(rays);
-    light_queries = wave_sum(light_queries);
-    if (lane_id() == 0) {
-        if (live_n) atomicAdd(&ctr->live, live_n);
         if (rays) atomicAdd(&ctr->rays, (unsigned long long)rays);
         if (light_queries) atomicAdd(&ctr->light_queries, (unsigned long long)light_queries);
     }
@@ -1674,9 +1567,38 @@ struct mrt_scene {
     int64_t opt_trace_zero = 0;
     int64_t opt_compact = 1;
     int64_t opt_traversal = 0;  // 0 auto, 1 per-lane, 2 wave-synchronous
-    int64_t opt_sort = 0;       // workgroup-local sort by shading class
+    int features = 0;           // FEAT_* bits the scene needs
     std::mutex mu;
 };
+
+// Feature sets the kernels are instantiated for, smallest first; the last one covers everything.
+template <int... M>
+struct FeatList {};
+using KernelFeats = FeatList<0, FEAT_MEDIUM, FEAT_SPHERE | FEAT_MEDIUM | FEAT_SPECULAR | FEAT_TEXTURE | FEAT_SKY,
+                             FEAT_OCTREE | FEAT_SKY, FEAT_ALL>;
+// Calls f(std::integral_constant<int, M>) for the first instantiated set M that covers `need`.
+template <class F, int M0, int... M>
+static void dispatch_feat(int need, FeatList<M0, M...>, F&& f) {
+    if ((need & ~M0) == 0 || sizeof...(M) == 0) {
+        f(std::integral_constant<int, M0>{});
+        return;
+    }
+    if constexpr (sizeof...(M) > 0) dispatch_feat(need, FeatList<M...>{}, f);
+}
+static int scene_features(const FlatScene& f) {
+    int need = 0;
+    for (const DShape& sh : f.shapes) {
+        if (sh.kind == MRT_SHAPE_OCTREE) need |= FEAT_OCTREE;
+        if (sh.kind == MRT_SHAPE_SPHERE || sh.kind == MRT_SHAPE_MOVING_SPHERE) need |= FEAT_SPHERE;
+        if (sh.kind == MRT_SHAPE_CONSTANT_MEDIUM) need |= FEAT_MEDIUM;
+    }
+    for (const DMaterial& m : f.materials)
+        if (m.kind == MRT_MAT_METAL || m.kind == MRT_MAT_DIELECTRIC) need |= FEAT_SPECULAR;
+    for (const DTexture& t : f.textures)
+        if (t.kind != MRT_TEX_SOLID) need |= FEAT_TEXTURE;
+    if (f.background.kind != MRT_BG_CONSTANT || f.sun.has_sun) need |= FEAT_SKY;
+    return need;
+}
 
 // Trees of at most this many nodes are walked wave-synchronously.
 constexpr int WAVE_SYNC_MAX_NODES = 64;
@@ -1792,24 +1714,13 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
         HIP_TRY(hipEventRecord(ek0, stream));
         {
             const dim3 grid((active + BLOCK - 1) / BLOCK), block(BLOCK);
-            const bool oct = !sc->flat.octrees.empty();
-            if (sc->opt_sort && (active % BLOCK) == 0) {
-                if (wave_sync && !oct)
-                    hipLaunchKernelGGL((k_segments_sorted<true, 0>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
-                else if (wave_sync && oct)
-                    hipLaunchKernelGGL((k_segments_sorted<true, FEAT_OCTREE>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
-                else if (!oct)
-                    hipLaunchKernelGGL((k_segments_sorted<false, 0>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
+            dispatch_feat(sc->features, KernelFeats{}, [&](auto feat) {
+                constexpr int FT = decltype(feat)::value;
+                if (wave_sync)
+                    hipLaunchKernelGGL((k_segments<true, FT>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
                 else
-                    hipLaunchKernelGGL((k_segments_sorted<false, FEAT_OCTREE>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
-            } else if (wave_sync && !oct)
-                hipLaunchKernelGGL((k_segments<true, 0>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
-            else if (wave_sync && oct)
-                hipLaunchKernelGGL((k_segments<true, FEAT_OCTREE>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
-            else if (!oct)
-                hipLaunchKernelGGL((k_segments<false, 0>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
-            else
-                hipLaunchKernelGGL((k_segments<false, FEAT_OCTREE>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
+                    hipLaunchKernelGGL((k_segments<false, FT>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
+            });
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ek1, stream));
@@ -1888,6 +1799,7 @@ mrt_scene* mrt_scene_create(const mrt_scene_desc* desc, int device, char* err, s
         return nullptr;
     }
     sc->device = device;
+    sc->features = scene_features(sc->flat);
     if (device >= 0) {
         int n = mrt_device_count();
         if (n <= 0) {
@@ -1941,8 +1853,6 @@ int mrt_scene_set_option(mrt_scene* scene, const char* name, int64_t value) {
         scene->opt_trace_zero = value ? 1 : 0;
     } else if (n == "compaction") {
         scene->opt_compact = value ? 1 : 0;
-    } else if (n == "sort") {
-        scene->opt_sort = value ? 1 : 0;
     } else if (n == "traversal") {
         if (value < 0 || value > 2) return set_error(MRT_ERR_INVALID_ARGUMENT, "traversal must be 0, 1 or 2");
         scene->opt_traversal = value;
@@ -1999,15 +1909,14 @@ int mrt_trace_rays(mrt_scene* scene, const double* rays, size_t n, uint64_t seed
     HIP_TRY(hipMemcpy(drays, rays, sizeof(double) * 7 * n, hipMemcpyHostToDevice));
     {
         const dim3 grid(((uint32_t)n + BLOCK - 1) / BLOCK), block(BLOCK);
-        const bool oct = !scene->flat.octrees.empty(), ws = use_wave_sync(scene);
-        if (ws && !oct)
-            hipLaunchKernelGGL((k_trace_rays<true, 0>), grid, block, 0, 0, scene->view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
-        else if (ws && oct)
-            hipLaunchKernelGGL((k_trace_rays<true, FEAT_OCTREE>), grid, block, 0, 0, scene->view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
-        else if (!oct)
-            hipLaunchKernelGGL((k_trace_rays<false, 0>), grid, block, 0, 0, scene->view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
-        else
-            hipLaunchKernelGGL((k_trace_rays<false, FEAT_OCTREE>), grid, block, 0, 0, scene->view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
+        const bool ws = use_wave_sync(scene);
+        dispatch_feat(scene->features, KernelFeats{}, [&](auto feat) {
+            constexpr int FT = decltype(feat)::value;
+            if (ws)
+                hipLaunchKernelGGL((k_trace_rays<true, FT>), grid, block, 0, 0, scene->view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
+            else
+                hipLaunchKernelGGL((k_trace_rays<false, FT>), grid, block, 0, 0, scene->view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
+        });
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());

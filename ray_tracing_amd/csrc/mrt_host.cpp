@@ -395,6 +395,7 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
                     return fail(err, MRT_ERR_UNSUPPORTED, "medium: unsupported boundary shape");
                 if (!(sh.p[0] != 0.0)) return fail(err, MRT_ERR_INVALID_ARGUMENT, "medium: zero density");
                 s.has_medium = true;
+                ds.p[9] = -1.0 / sh.p[0];  // ConstantMedium::new, constant_medium.rs:27-32
                 break;
             }
             case MRT_SHAPE_OCTREE:
@@ -524,7 +525,6 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
             r.skip = s.node_skip[i];
             r.flags = s.node_flags[i];
             r.kind = -1;
-            r.simple = 1;
             if (r.object >= 0) {
                 const DObject& ob = s.objects[(size_t)r.object];
                 const DShape* sh = &s.shapes[(size_t)ob.shape];
@@ -536,12 +536,10 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
                     const DShape* b = &s.shapes[(size_t)sh->boundary];
                     r.kind2 = b->kind;
                     std::memcpy(r.p, b->p, sizeof(r.p));
-                    if (b->kind == MRT_SHAPE_MOVING_SPHERE) r.simple = 0;  // needs all ten slots
-                    r.p[9] = -1.0 / sh->p[0];  // ConstantMedium::new, constant_medium.rs:27-32
+                    r.p[9] = sh->p[9];  // -1/density (a boundary uses at most slots 0..8)
                 } else {
                     std::memcpy(r.p, sh->p, sizeof(r.p));
                 }
-                if (r.flags & NODE_DYNAMIC_BOX) r.simple = 0;  // time-dependent boxes use the object tables
             }
         }
     }

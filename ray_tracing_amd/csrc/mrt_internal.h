@@ -31,7 +31,7 @@ struct DShape {
     int32_t material;
     int32_t boundary;
     int32_t octree;
-    double p[10];
+    double p[10];  // parameter slots as in mrt_shape; media also carry p[9] = -1/density
 };
 
 struct DMaterial {
@@ -92,8 +92,8 @@ struct DNodeRec {
     int32_t identity;  // object transform is the identity
     int32_t kind2;     // media: kind of the boundary shape
     int32_t octree;    // octree index for OCTREE leaves
-    int32_t simple;    // 1: the record is complete (otherwise the walk falls back to the object tables)
-    double p[10];      // shape parameters (media: the boundary's); p[9] = -1/density for media
+    int32_t pad;
+    double p[10];      // shape parameters (media: the boundary's, and p[9] = -1/density)
     Affine to_object;  // world -> object (used when !identity)
 };
 static_assert(sizeof(DNodeRec) == 256, "DNodeRec must be 256 bytes");
