@@ -17,6 +17,11 @@ lib: $(LIB)
 $(LIB): $(CSRC)/mrt_device.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_internal.h include/mrt.h
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/mrt_device.hip $(CSRC)/mrt_host.cpp
 
+# Diagnostic build: in-kernel cycle stamps per region of the segment kernel (never benchmarked).
+stamps: ray_tracing_amd/libmrt_stamps.so
+ray_tracing_amd/libmrt_stamps.so: $(CSRC)/mrt_device.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_internal.h include/mrt.h
+	$(HIPCC) $(HIPFLAGS) -DMRT_STAMPS -shared -o $@ $(CSRC)/mrt_device.hip $(CSRC)/mrt_host.cpp
+
 oracle: $(ORACLE)
 
 # -march=native is deliberately NOT used: the .so is built here and run on the GPU box's host.
@@ -26,4 +31,4 @@ $(ORACLE): oracle/cpu_ref.cpp oracle/octree_api.cpp oracle/octree_ref.h include/
 clean:
 	rm -f $(LIB) $(ORACLE)
 
-.PHONY: all lib oracle clean
+.PHONY: all lib oracle stamps clean

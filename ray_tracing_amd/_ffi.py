@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmrt.so")
+# MRT_LIBRARY selects another build of the same ABI (e.g. the diagnostic libmrt_stamps.so)
+LIB_PATH = os.environ.get("MRT_LIBRARY") or os.path.join(_HERE, "libmrt.so")
 
 MRT_ABI_VERSION = 1
 

@@ -45,10 +45,8 @@ struct SceneView {
     int32_t n_objects;
     int32_t n_lights;
     int32_t trace_zero_throughput;
-    const DObject* objects;
-    const DObject* lights;
-    const DShape* shapes;
-    const DMaterial* materials;
+    const DObjRec* objects;  // one record per object (shape, transform, material)
+    const DObjRec* lights;   // the light list, same record type
     const DTexture* textures;
     const DImage* images;
     const float* image_pool;
@@ -67,14 +65,48 @@ struct Pool {
     uint64_t* key;
     int32_t* seg;  // >= 0: index of the next segment of a live path; < 0: free slot
 };
+// Work items (pixel-samples) are handed out in chunks: a wave takes WORK_CHUNK consecutive items
+// from the global counter with one atomic and serves its lanes from that range; what is left of
+// the range when a launch ends is kept per wave ([next, end) pairs) for the next launch.
+constexpr uint32_t WORK_CHUNK = 512;
 
+enum : int { ST_REGEN = 0, ST_TRAVERSE, ST_LEAF, ST_SURFACE, ST_LAMBERT_GEN, ST_LIGHT_VALUE, ST_SHADE, ST_ACCUM, ST_TOTAL, ST_MEDIUM_TAIL, ST_CLAIM, ST_COUNT };
 struct Counters {
     unsigned long long work_next;
     unsigned long long rays;
     unsigned long long light_queries;
     unsigned int live;
     unsigned int compacted;
+    unsigned long long held;  // work items claimed by waves but not started when the launch ended
+    unsigned long long stamps[ST_COUNT];  // diagnostic build only
 };
+
+// Diagnostic build (-DMRT_STAMPS): wave-level cycle shares of the segment kernel's regions.
+// A region's cycles are added by the first active lane only, so the sum over lanes and waves is
+// the total wave time spent in the region. No stamp executes in the regular build.
+#ifdef MRT_STAMPS
+struct Stamps {
+    unsigned long long acc[ST_COUNT];
+};
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+__device__ __forceinline__ void stamp_add(Stamps& st, int i, unsigned long long t0) {
+    unsigned long long d = stamp_now() - t0;
+    unsigned long long m = __ballot(1);
+    if ((int)__lane_id() == __ffsll((long long)m) - 1) st.acc[i] += d;
+}
+#define REGION_BEGIN(name) unsigned long long name##_t0 = stamp_now()
+#define REGION_END(st, i, name) stamp_add(st, i, name##_t0)
+#else
+struct Stamps {};
+#define REGION_BEGIN(name) ((void)0)
+#define REGION_END(st, i, name) ((void)0)
+#endif
 
 struct RenderParams {
     float* accum;
@@ -84,7 +116,18 @@ struct RenderParams {
     uint64_t seed, first_sample;
     uint32_t n_slots;
     uint32_t steps;
+    double inv_npix_strip, inv_strip_w;  // reciprocals for the work-index decomposition
 };
+
+// w -> (w / d, w % d) for w < 2^53, d < 2^32 and a quotient < 2^32, without an integer division:
+// the f64 estimate is off by at most one, which the remainder check repairs.
+__device__ __forceinline__ void divmod_u32(unsigned long long w, uint32_t d, double inv_d, uint32_t& q, uint32_t& r) {
+    uint32_t qe = (uint32_t)((double)w * inv_d);
+    long long rem = (long long)(w - (unsigned long long)qe * d);
+    if (rem < 0) qe--, rem += d;
+    else if (rem >= (long long)d) qe++, rem -= d;
+    q = qe, r = (uint32_t)rem;
+}
 
 // Compile-time scene features. The segment kernel is instantiated for a handful of feature sets
 // and a scene runs on the smallest instantiation that covers what it contains, so a scene pays
@@ -299,19 +342,19 @@ __device__ __forceinline__ bool aabb_hit(D3 mn, D3 mx, const RayD& r, D3 inv_d, 
     {
         double t0 = (mn.x - r.o.x) * inv_d.x, t1 = (mx.x - r.o.x) * inv_d.x;
         if (inv_d.x < 0.0) { double s = t0; t0 = t1; t1 = s; }
-        double lo = t0 > t_min ? t0 : t_min, hi = t1 < t_max ? t1 : t_max;
+        double lo = fmax(t0, t_min), hi = fmin(t1, t_max);  // a NaN slab bound (0 * inf) leaves t_min / t_max
         if (hi < lo) return false;
     }
     {
         double t0 = (mn.y - r.o.y) * inv_d.y, t1 = (mx.y - r.o.y) * inv_d.y;
         if (inv_d.y < 0.0) { double s = t0; t0 = t1; t1 = s; }
-        double lo = t0 > t_min ? t0 : t_min, hi = t1 < t_max ? t1 : t_max;
+        double lo = fmax(t0, t_min), hi = fmin(t1, t_max);  // a NaN slab bound (0 * inf) leaves t_min / t_max
         if (hi < lo) return false;
     }
     {
         double t0 = (mn.z - r.o.z) * inv_d.z, t1 = (mx.z - r.o.z) * inv_d.z;
         if (inv_d.z < 0.0) { double s = t0; t0 = t1; t1 = s; }
-        double lo = t0 > t_min ? t0 : t_min, hi = t1 < t_max ? t1 : t_max;
+        double lo = fmax(t0, t_min), hi = fmin(t1, t_max);  // a NaN slab bound (0 * inf) leaves t_min / t_max
         if (hi < lo) return false;
     }
     return true;
@@ -561,24 +604,12 @@ __device__ __forceinline__ bool leaf_hit(const SceneView& sv, int kind, int bkin
     }
     return false;
 }
-// Leaf test from the object / shape tables.
-template <int FEAT, class OP, class SP>
-__device__ __forceinline__ bool object_hit(const SceneView& sv, OP ob, SP shapes, const RayD& ray, D3 inv_world,
-                                           double t_min, double t_max, const Rng& g, uint32_t medium_dim, double& t,
-                                           int& sub, D3& pos) {
-    SP sh = shapes + ob->shape;
-    const int kind = sh->kind;
-    auto p = &sh->p[0];
-    int bkind = 0;
-    double nid = 0.0;
-    if constexpr ((FEAT & FEAT_MEDIUM) != 0) {
-        if (kind == MRT_SHAPE_CONSTANT_MEDIUM) {
-            SP b = shapes + sh->boundary;
-            p = &b->p[0], bkind = b->kind, nid = sh->p[9];
-        }
-    }
-    return leaf_hit<FEAT>(sv, kind, bkind, sh->octree, p, nid, ob->identity != 0, &ob->to_object, ray, inv_world, t_min,
-                          t_max, g, medium_dim, t, sub, pos);
+// Leaf test from an object record.
+template <int FEAT, class OP>
+__device__ __forceinline__ bool object_hit(const SceneView& sv, OP ob, const RayD& ray, D3 inv_world, double t_min,
+                                           double t_max, const Rng& g, uint32_t medium_dim, double& t, int& sub, D3& pos) {
+    return leaf_hit<FEAT>(sv, ob->kind, ob->gkind, ob->octree, &ob->p[0], ob->p[9], ob->identity != 0, &ob->to_object, ray,
+                          inv_world, t_min, t_max, g, medium_dim, t, sub, pos);
 }
 // Leaf test of the wave-synchronous walk from a self-contained node record (scalar operands).
 template <int FEAT, class RP>
@@ -590,11 +621,9 @@ __device__ __forceinline__ bool node_hit(const SceneView& sv, RP r, const RayD& 
 
 // Leaf box of a MovingSphere-based object for the time window (t0, t1) the reference passes
 // (bvh.rs:142-145,180; sphere.rs:175-186; hittable.rs:239-282).
-template <class OP, class SP>
-__device__ void dynamic_leaf_box(OP ob, SP shapes, double t0, double t1, D3& mn, D3& mx) {
-    SP sh = shapes + ob->shape;
-    if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = shapes + sh->boundary;
-    auto p = sh->p;
+template <class OP>
+__device__ void dynamic_leaf_box(OP ob, double t0, double t1, D3& mn, D3& mx) {
+    auto p = ob->p;
     D3 c0 = moving_center(p, t0), c1 = moving_center(p, t1);
     D3 r{p[0], p[0], p[0]};
     D3 lo0 = c0 - r, hi0 = c0 + r, lo1 = c1 - r, hi1 = c1 + r;
@@ -636,23 +665,23 @@ __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng
         D3 mn{sv.bmin_x[i], sv.bmin_y[i], sv.bmin_z[i]};
         D3 mx{sv.bmax_x[i], sv.bmax_y[i], sv.bmax_z[i]};
         if constexpr ((FEAT & FEAT_SPHERE) != 0) {
-            if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(sv.objects + obj, sv.shapes, t_min, closest, mn, mx);
+            if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(sv.objects + obj, t_min, closest, mn, mx);
         }
         if (!aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
             i = sv.node_skip[i];
             continue;
         }
         if (obj >= 0) {
-            const DObject* ob = sv.objects + obj;
+            const DObjRec* ob = sv.objects + obj;
             bool is_medium = false;
-            if constexpr ((FEAT & FEAT_MEDIUM) != 0) is_medium = sv.shapes[ob->shape].kind == MRT_SHAPE_CONSTANT_MEDIUM;
+            if constexpr ((FEAT & FEAT_MEDIUM) != 0) is_medium = ob->kind == MRT_SHAPE_CONSTANT_MEDIUM;
             const int rounds = (flags & NODE_TWICE) ? 2 : 1;
 #pragma nounroll
             for (int round = 0; round < rounds; ++round) {
                 if (round == 1 && !aabb_hit(mn, mx, ray, inv_d, t_min, closest)) break;
                 double t;
                 int sub;
-                if (object_hit<FEAT>(sv, ob, sv.shapes, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
+                if (object_hit<FEAT>(sv, ob, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
                     closest = t, best_obj = obj, best_sub = sub;
                 }
                 if (is_medium) medium_ordinal++;
@@ -674,7 +703,7 @@ __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng
 // (`resume`); a subtree no lane wants is skipped for the whole wave by a ballot. Must be called
 // by every lane of the wave; lanes with live == false only follow along.
 template <int FEAT>
-__device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng& g, bool live, HitD& out) {
+__device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng& g, bool live, HitD& out, Stamps& st) {
     const double t_min = (double)0.001f;
     double closest = (double)FLT_MAX;
     int best_obj = -1, best_sub = 0;
@@ -696,7 +725,7 @@ __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng
         if (i >= resume) {
             if constexpr ((FEAT & FEAT_SPHERE) != 0) {
                 if (flags & NODE_DYNAMIC_BOX)
-                    dynamic_leaf_box(as_const(sv.objects) + obj, as_const(sv.shapes), t_min, closest, mn, mx);
+                    dynamic_leaf_box(as_const(sv.objects) + obj, t_min, closest, mn, mx);
             }
             pass = aabb_hit(mn, mx, ray, inv_d, t_min, closest);
             if (!pass) resume = skip;
@@ -706,6 +735,7 @@ __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng
             continue;
         }
         if (obj >= 0) {
+            REGION_BEGIN(leaf);
             bool is_medium = false;
             if constexpr ((FEAT & FEAT_MEDIUM) != 0) is_medium = r->kind == MRT_SHAPE_CONSTANT_MEDIUM;
             const int rounds = (flags & NODE_TWICE) ? 2 : 1;
@@ -721,6 +751,7 @@ __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng
                     if (is_medium) medium_ordinal++;
                 }
             }
+            REGION_END(st, is_medium ? ST_MEDIUM_TAIL : ST_LEAF, leaf);
         }
         i = i + 1;
     }
@@ -739,7 +770,7 @@ struct Surface {
     D3 org_obj;   // object-space ray origin
     double t;
     double time;  // object-space ray time (= world ray time)
-    int material;
+    int voxel;  // octree hits: index of the voxel record, else -1
     int sub;
     bool front_face;  // as the material sees it (object space; `true` for media, constant_medium.rs:66-72)
 };
@@ -760,8 +791,8 @@ __device__ __forceinline__ void rect_uv(double a0, double a1, double b0, double 
     v = (b - b0) / (b1 - b0);
 }
 // Texture coordinates of the hit; evaluated only for textures that read them.
-template <int FEAT, class SP>
-__device__ void surface_uv(SP sh, const Surface& s, double& u, double& v) {
+template <int FEAT, class OP>
+__device__ void surface_uv(OP sh, const Surface& s, double& u, double& v) {
     auto p = sh->p;
     u = 0.0, v = 0.0;
     switch (sh->kind) {
@@ -780,17 +811,17 @@ __device__ void surface_uv(SP sh, const Surface& s, double& u, double& v) {
         default: break;  // ConstantMedium: uv (0,0)
     }
 }
-template <int FEAT, class OP, class SP>
-__device__ void surface_at(OP ob, SP shapes, const RayD& ray, double t, int sub, D3 oct_pos, Surface& s) {
+template <int FEAT, class OP>
+__device__ void surface_at(OP ob, const RayD& ray, double t, int sub, D3 oct_pos, Surface& s) {
     RayD sr = ob->identity ? ray : xform_ray(&ob->to_object, false, ray);
-    SP sh = shapes + ob->shape;
+    OP sh = ob;
     auto p = sh->p;
     s.pos_obj = ray_at(sr, t);
     s.dir_obj = sr.d;
     s.org_obj = sr.o;
     s.t = t;
     s.time = sr.time;
-    s.material = sh->material;
+    s.voxel = -1;
     s.sub = sub;
     s.n_obj = {1.0, 0.0, 0.0};
     switch (sh->kind) {
@@ -814,7 +845,7 @@ __device__ void surface_at(OP ob, SP shapes, const RayD& ray, double t, int sub,
             double sg = (code & 1) ? 1.0 : -1.0;
             s.n_obj = {code < 2 ? sg : 0.0, (code == 2 || code == 3) ? sg : 0.0, code >= 4 ? sg : 0.0};
             s.pos_obj = oct_pos;
-            s.material = -1 - sub / 6;  // voxel record index, negative = VoxelMaterial::Lambertian
+            s.voxel = sub / 6;  // VoxelMaterial::Lambertian record
             break;
         }
         default: break;  // ConstantMedium: normal (1,0,0), front_face true for the phase function
@@ -842,11 +873,10 @@ __device__ __forceinline__ uint32_t f64_as_index(double v, uint32_t hi) {  // Ru
     return (uint32_t)v;
 }
 template <int FEAT>
-__device__ F3 texture_color(const SceneView& sv, int tex, const DShape* sh, const Surface& sf) {
-    if constexpr ((FEAT & FEAT_TEXTURE) == 0) {  // every texture of the scene is a SolidColor
-        const DTexture& t = sv.textures[tex];
-        return {t.color[0], t.color[1], t.color[2]};
-    }
+__device__ F3 texture_color(const SceneView& sv, const DObjRec* sh, const Surface& sf) {
+    // SolidColor textures are folded into the object record
+    if ((FEAT & FEAT_TEXTURE) == 0 || sh->tex_solid) return {sh->color[0], sh->color[1], sh->color[2]};
+    const int tex = sh->texture;
     F3 acc{1.f, 1.f, 1.f};
     const D3 pos = sf.pos_obj;
     double u = 0.0, v = 0.0;
@@ -911,13 +941,10 @@ __device__ __forceinline__ double rect_prob(double a0, double a1, double b0, dou
     double area = (a1 - a0) * (b1 - b0);
     return dot(to_light, to_light) * rcp_fast(cos_alpha * area);
 }
-template <int FEAT, class SP>
-__device__ double shape_prob(SP shapes, SP sh, const RayD& r) {
-    if constexpr ((FEAT & FEAT_MEDIUM) != 0) {
-        if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = shapes + sh->boundary;  // constant_medium.rs:98-100
-    }
+template <int FEAT, class OP>
+__device__ double shape_prob(OP sh, const RayD& r) {
     auto p = sh->p;
-    switch (sh->kind) {
+    switch (sh->gkind) {  // a medium answers for its boundary (constant_medium.rs:98-100)
         case MRT_SHAPE_SPHERE: {
             if constexpr ((FEAT & FEAT_SPHERE) != 0) {
                 double area = M_PI * (p[0] * p[0]);
@@ -960,13 +987,10 @@ __device__ __forceinline__ void rect_generate(double a0, double a1, double b0, d
     o.direction = end_point - origin;
     o.end_point = end_point;
 }
-template <int FEAT, class SP>
-__device__ void shape_generate(SP shapes, SP sh, D3 origin, double time, const Rng& g, AreaInfo& o) {
-    if constexpr ((FEAT & FEAT_MEDIUM) != 0) {
-        if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) sh = shapes + sh->boundary;  // constant_medium.rs:101-103
-    }
+template <int FEAT, class OP>
+__device__ void shape_generate(OP sh, D3 origin, double time, const Rng& g, AreaInfo& o) {
     auto p = sh->p;
-    switch (sh->kind) {
+    switch (sh->gkind) {  // a medium answers for its boundary (constant_medium.rs:101-103)
         case MRT_SHAPE_SPHERE: {  // sphere.rs:72-87
             if constexpr ((FEAT & FEAT_SPHERE) != 0) {
                 D3 sd = rand_unit_vec(g, MRT_DIM_LIGHT_SPHERE);
@@ -1001,11 +1025,10 @@ __device__ void shape_generate(SP shapes, SP sh, D3 origin, double time, const R
     }
 }
 // Object::generate_ray_in_area, hittable.rs:289-312
-template <int FEAT, class OP, class SP>
-__device__ void object_generate(OP ob, SP shapes, D3 origin, double time, const Rng& g, AreaInfo& out) {
-    SP sh = shapes + ob->shape;
+template <int FEAT, class OP>
+__device__ void object_generate(OP ob, D3 origin, double time, const Rng& g, AreaInfo& out) {
     if (ob->identity) {
-        shape_generate<FEAT>(shapes, sh, origin, time, g, out);
+        shape_generate<FEAT>(ob, origin, time, g, out);
         // the reference still routes every vector through the (identity) inverse
         D3 o = out.to_area.o;
         out.to_area.d = (o + out.to_area.d) - o;
@@ -1014,7 +1037,7 @@ __device__ void object_generate(OP ob, SP shapes, D3 origin, double time, const 
         return;
     }
     AreaInfo a;
-    shape_generate<FEAT>(shapes, sh, apply(&ob->to_object, origin), time, g, a);
+    shape_generate<FEAT>(ob, apply(&ob->to_object, origin), time, g, a);
     auto inv = &ob->to_world;
     out.end_point = apply(inv, a.end_point);
     out.to_area = xform_ray(inv, false, a.to_area);
@@ -1035,16 +1058,15 @@ __device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng&
     int best = -1, best_sub = 0;
     uint32_t ordinal = 0;
     auto lights = as_const(sv.lights);  // the loop index is wave-uniform: scalar loads
-    auto cshapes = as_const(sv.shapes);
     D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
     for (int i = 0; i < sv.n_lights; ++i) {
         auto lob = lights + i;
         double t;
         int sub;
         D3 unused_pos;
-        bool h = object_hit<LF>(sv, lob, cshapes, ray, inv_d, ray.time, DBL_MAX, g, MRT_DIM_LIGHT_QUERY_MEDIUM + ordinal, t, sub, unused_pos);
+        bool h = object_hit<LF>(sv, lob, ray, inv_d, ray.time, DBL_MAX, g, MRT_DIM_LIGHT_QUERY_MEDIUM + ordinal, t, sub, unused_pos);
         if constexpr ((LF & FEAT_MEDIUM) != 0) {
-            if (cshapes[lob->shape].kind == MRT_SHAPE_CONSTANT_MEDIUM) ordinal++;
+            if (lob->kind == MRT_SHAPE_CONSTANT_MEDIUM) ordinal++;
         }
         if (!h) continue;
         if (!any || !(best_t < t)) {  // reduce(|acc, x| if acc.t < x.t { acc } else { x })
@@ -1052,9 +1074,9 @@ __device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng&
         }
     }
     if (!any) return false;
-    const DObject* ob = sv.lights + best;
+    const DObjRec* ob = sv.lights + best;
     Surface s;
-    surface_at<LF>(ob, sv.shapes, ray, best_t, best_sub, D3{0.0, 0.0, 0.0}, s);
+    surface_at<LF>(ob, ray, best_t, best_sub, D3{0.0, 0.0, 0.0}, s);
     D3 hit_pos = point_to_world(ob, s.pos_obj);
     D3 hit_n = normal_to_world(ob, s.n_obj);
     D3 to_light = hit_pos - ray.o;
@@ -1063,7 +1085,7 @@ __device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng&
         // Object::prob applies the INVERSE transform to the ray (hittable.rs:284-287)
         RayD pr{ray.o, normalize(to_light), best_t};
         RayD tr = xform_ray(&ob->to_world, ob->identity != 0, pr);
-        value = shape_prob<LF>(sv.shapes, sv.shapes + ob->shape, tr);
+        value = shape_prob<LF>(ob, tr);
     } else {
         value = 0.0;
     }
@@ -1089,7 +1111,8 @@ __device__ __forceinline__ D3 sun_direction(const mrt_sun& s) {  // sun.rs:17-20
 // LambertianPDF::generate, pdf.rs:234-282. Returns false for None.
 template <int FEAT>
 __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double incoming_time, D3 hit_point,
-                                    const Rng& g, uint32_t& light_queries, D3& out_dir, double& out_value) {
+                                    const Rng& g, uint32_t& light_queries, D3& out_dir, double& out_value, Stamps& st) {
+    REGION_BEGIN(gen);
     Onb uvw = onb_from_w(pdf_normal);
     uint32_t r = rand_u32(g, 0, 3, MRT_DIM_PDF_CHOICE);
     D3 dir;
@@ -1109,7 +1132,7 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
         if (sv.n_lights == 0) return false;
         uint32_t idx = rand_u32(g, 0, (uint32_t)sv.n_lights, MRT_DIM_LIGHT_INDEX);
         AreaInfo ai;
-        object_generate<(FEAT & ~FEAT_OCTREE)>(sv.lights + idx, sv.shapes, hit_point, incoming_time, g, ai);
+        object_generate<(FEAT & ~FEAT_OCTREE)>(sv.lights + idx, hit_point, incoming_time, g, ai);
         D3 nd = normalize(ai.to_area.d);
         double light_cos = fabs(dot(nd, ai.normal));
         double dist_squared = dot(ai.direction, ai.direction);
@@ -1133,12 +1156,15 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
             own = area / (4.0 * M_PI);
         }
     }
+    REGION_END(st, ST_LAMBERT_GEN, gen);
     RayD value_ray{hit_point, dir, 0.0};
     double sum = 0.0;
     int total = 0;
     if (r != 1) {  // light_pdf.value
+        REGION_BEGIN(lv);
         double lv;
         if (light_pdf_value<FEAT>(sv, value_ray, g, light_queries, lv)) sum += lv, total++;
+        REGION_END(st, ST_LIGHT_VALUE, lv);
     }
     if (r != 0) {  // sin_pdf.value, pdf.rs:32-39 (direction NOT normalised here)
         double c = dot(dir, uvw.w);
@@ -1204,7 +1230,8 @@ __device__ RayD camera_ray(const SceneView& sv, uint32_t x, uint32_t y, uint32_t
     RayD r;
     r.o = ld3(c.origin);
     r.d = ld3(c.lower_left_corner) + s * ld3(c.horizontal) + t * ld3(c.vertical) - ld3(c.origin) - offset;
-    r.time = rand_scalar(g, c.start_time, c.end_time, MRT_DIM_TIME);
+    // rand_scalar(start, end) is start + u * 0 when the shutter interval is empty
+    r.time = c.start_time == c.end_time ? c.start_time : rand_scalar(g, c.start_time, c.end_time, MRT_DIM_TIME);
     return r;
 }
 
@@ -1219,30 +1246,31 @@ __device__ __forceinline__ D3 reflect(D3 v, D3 n) { return v - 2.0 * dot(v, n) *
 // Material response at the nearest hit `h` (or the background when `hit` is false).
 template <int FEAT>
 __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, const HitD& h, bool hit,
-                            F3& radiance, uint32_t& light_queries) {
+                            F3& radiance, uint32_t& light_queries, Stamps& st) {
     radiance = {0.f, 0.f, 0.f};
     if (!hit) {
         F3 bg = background_color<FEAT>(sv, ray);
         radiance = thr * bg;
         return false;
     }
-    const DObject* ob = sv.objects + h.obj;
+    REGION_BEGIN(surf);
+    const DObjRec* ob = sv.objects + h.obj;
     Surface s;
-    surface_at<FEAT>(ob, sv.shapes, ray, h.t, h.sub, h.pos, s);
+    surface_at<FEAT>(ob, ray, h.t, h.sub, h.pos, s);
     // VoxelMaterial::Lambertian (fast_oct_tree/voxel.rs:85-90) behaves as Lambertian with a constant albedo
-    const bool voxel_mat = (FEAT & FEAT_OCTREE) != 0 && s.material < 0;
-    const DMaterial& m = sv.materials[voxel_mat ? 0 : s.material];
-    const int mkind = voxel_mat ? (int)MRT_MAT_LAMBERTIAN : m.kind;
+    const bool voxel_mat = (FEAT & FEAT_OCTREE) != 0 && s.voxel >= 0;
+    const int mkind = voxel_mat ? (int)MRT_MAT_LAMBERTIAN : ob->mat_kind;
     // Texture value of the material (emitted colour / albedo); evaluated once for every material kind.
-    F3 att{m.color[0], m.color[1], m.color[2]};
+    F3 att{ob->color[0], ob->color[1], ob->color[2]};
     if (voxel_mat) {
         if constexpr ((FEAT & FEAT_OCTREE) != 0) {
-            const mrt_voxel& vx = sv.oct_voxels[-1 - s.material];
+            const mrt_voxel& vx = sv.oct_voxels[s.voxel];
             att = {vx.albedo[0], vx.albedo[1], vx.albedo[2]};
         }
     } else if (mkind != MRT_MAT_DIELECTRIC) {
-        att = texture_color<FEAT>(sv, m.texture, sv.shapes + ob->shape, s);
+        att = texture_color<FEAT>(sv, ob, s);
     }
+    REGION_END(st, ST_SURFACE, surf);
     // HitRecord::new (hittable.rs:414-448): emit first, else scatter, else nothing.
     switch (mkind) {
         case MRT_MAT_DIFFUSE_LIGHT: {  // material.rs:236-248
@@ -1254,7 +1282,7 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
             D3 n_w = normal_to_world(ob, s.n_obj);
             D3 dir;
             double value;
-            if (!lambertian_generate<FEAT>(sv, s.n_obj, ray.time, pos_w, g, light_queries, dir, value)) return false;
+            if (!lambertian_generate<FEAT>(sv, s.n_obj, ray.time, pos_w, g, light_queries, dir, value, st)) return false;
             double cosine = dot(n_w, normalize(dir));  // Lambertian::scattering_pdf_fn, material.rs:30-41
             if (cosine < 0.0) return false;
             double scattering_pdf = cosine * INV_PI;
@@ -1269,14 +1297,14 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
                 D3 reflected = reflect(normalize(s.dir_obj), s.n_obj);
                 if (!(dot(reflected, s.n_obj) > 0.0)) return false;
                 thr = thr * att;
-                ray = {s.pos_obj, reflected + m.fuzz * rand_unit_vec(g, MRT_DIM_METAL_FUZZ), s.time};
+                ray = {s.pos_obj, reflected + ob->fuzz * rand_unit_vec(g, MRT_DIM_METAL_FUZZ), s.time};
                 break;
             }
             return false;
         }
         case MRT_MAT_DIELECTRIC: {  // material.rs:141-196
             if constexpr ((FEAT & FEAT_SPECULAR) != 0) {
-                double ratio = s.front_face ? 1.0 / m.index_refraction : m.index_refraction;
+                double ratio = s.front_face ? 1.0 / ob->index_refraction : ob->index_refraction;
                 D3 unit = normalize(s.dir_obj);
                 double cos_theta = fmin(dot(s.n_obj, -1.0 * unit), 1.0);
                 double sin_theta = sqrt(1.0 - cos_theta * cos_theta);
@@ -1315,18 +1343,23 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
 // path; with WAVE the traversal is wave-synchronous and every lane of the wave must call this.
 template <bool WAVE, int FEAT>
 __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, bool live, F3& radiance,
-                             uint32_t& rays, uint32_t& light_queries) {
+                             uint32_t& rays, uint32_t& light_queries, Stamps& st) {
     radiance = {0.f, 0.f, 0.f};
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     bool hit;
+    REGION_BEGIN(trav);
     if (WAVE) {
-        hit = nearest_hit_wave<FEAT>(sv, ray, g, live, h);
+        hit = nearest_hit_wave<FEAT>(sv, ray, g, live, h, st);
     } else {
         hit = live && nearest_hit_lane<FEAT>(sv, ray, g, h);
     }
+    REGION_END(st, ST_TRAVERSE, trav);
     if (!live) return false;
     rays++;
-    return shade_stage<FEAT>(sv, ray, thr, g, h, hit, radiance, light_queries);
+    REGION_BEGIN(shade);
+    bool cont = shade_stage<FEAT>(sv, ray, thr, g, h, hit, radiance, light_queries, st);
+    REGION_END(st, ST_SHADE, shade);
+    return cont;
 }
 
 // ============================================================== kernels
@@ -1343,7 +1376,8 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 // One launch = up to `steps` segments for every slot of the pool.
 template <bool WAVE, int FEAT>
-__global__ void __launch_bounds__(BLOCK, SEG_WAVES_PER_SIMD) k_segments(SceneView sv, Pool pool, RenderParams rp, Counters* ctr) {
+__global__ void __launch_bounds__(BLOCK, SEG_WAVES_PER_SIMD) k_segments(SceneView sv, Pool pool, RenderParams rp, Counters* ctr,
+                                                                     unsigned long long* wave_chunks) {
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     const bool in_range = slot < rp.n_slots;
     int32_t seg = -1;
@@ -1363,40 +1397,78 @@ __global__ void __launch_bounds__(BLOCK, SEG_WAVES_PER_SIMD) k_segments(SceneVie
         }
     }
     uint32_t rays = 0, light_queries = 0;
-    bool exhausted = false;
+    // this wave's share of the work range (wave-uniform)
+    const uint32_t wave_id = __builtin_amdgcn_readfirstlane(slot >> 6);
+    unsigned long long chunk_next = wave_chunks[2 * (size_t)wave_id];
+    unsigned long long chunk_end = wave_chunks[2 * (size_t)wave_id + 1];
+    chunk_next = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(chunk_next >> 32)) << 32) |
+                 __builtin_amdgcn_readfirstlane((uint32_t)chunk_next);
+    chunk_end = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(chunk_end >> 32)) << 32) |
+                __builtin_amdgcn_readfirstlane((uint32_t)chunk_end);
+    bool dry = false;  // the global counter has run past the end of the work
+    Stamps st{};
+    REGION_BEGIN(total);
     for (uint32_t step = 0; step < rp.steps; ++step) {
-        // ---- regeneration: free slots claim the next pixel-samples (one atomic per wave)
-        bool want = in_range && seg < 0 && !exhausted;
-        unsigned long long mask = __ballot(want);
-        if (mask) {
-            uint32_t n_want = (uint32_t)__popcll(mask);
-            unsigned long long base = 0;
-            int leader = __ffsll((long long)mask) - 1;
-            if ((int)lane_id() == leader) base = atomicAdd(&ctr->work_next, (unsigned long long)n_want);
-            base = __shfl(base, leader, 64);
-            if (want) {
-                unsigned long long w = base + (unsigned long long)__popcll(mask & ((1ULL << lane_id()) - 1ULL));
-                if (w < rp.n_work) {
-                    unsigned long long sample = w / rp.npix_strip;
-                    uint32_t pl = (uint32_t)(w - sample * rp.npix_strip);
-                    uint32_t y = pl / rp.strip_w;
-                    uint32_t x = rp.x0 + (pl - y * rp.strip_w);
-                    pixel = x + y * rp.width;
-                    key = path_key(rp.seed, (uint64_t)pixel, rp.first_sample + sample);
-                    Rng g{key, 0};
-                    ray = camera_ray(sv, x, y, rp.width, rp.height, g);
-                    thr = {1.f, 1.f, 1.f};
-                    seg = 0;
-                } else {
-                    exhausted = true;
+        // ---- regeneration: free slots take the next pixel-samples of the wave's range
+        REGION_BEGIN(regen);
+        const bool want = in_range && seg < 0;
+        const unsigned long long mask = __ballot(want);
+        if (mask && !(dry && chunk_next >= chunk_end)) {
+            const uint32_t n_want = (uint32_t)__popcll(mask);
+            const uint32_t rank = (uint32_t)__popcll(mask & ((1ULL << lane_id()) - 1ULL));
+            const unsigned long long avail = chunk_end - chunk_next;
+            unsigned long long w = ~0ULL;
+            if (avail >= n_want) {
+                w = chunk_next + rank;
+                chunk_next += n_want;
+            } else {
+                // serve what is left of the old range, then refill once (one atomic per wave)
+                unsigned long long nb = rp.n_work, ne = rp.n_work;
+                if (!dry) {
+                    unsigned long long base = 0;
+                    const int leader = __ffsll((long long)mask) - 1;
+                    REGION_BEGIN(claim);
+                    if ((int)lane_id() == leader) base = atomicAdd(&ctr->work_next, (unsigned long long)WORK_CHUNK);
+                    base = __shfl(base, leader, 64);
+                    REGION_END(st, ST_CLAIM, claim);
+                    if (base < rp.n_work) {
+                        nb = base;
+                        ne = base + WORK_CHUNK < rp.n_work ? base + WORK_CHUNK : rp.n_work;
+                    } else {
+                        dry = true;
+                    }
                 }
+                if (rank < avail) {
+                    w = chunk_next + rank;
+                } else {
+                    unsigned long long w2 = nb + (rank - avail);
+                    if (w2 < ne) w = w2;
+                }
+                unsigned long long taken = n_want - avail;
+                if (taken > ne - nb) taken = ne - nb;
+                chunk_next = nb + taken;
+                chunk_end = ne;
+            }
+            if (want && w != ~0ULL) {
+                uint32_t sample, pl, y, xs;
+                divmod_u32(w, (uint32_t)rp.npix_strip, rp.inv_npix_strip, sample, pl);
+                divmod_u32(pl, rp.strip_w, rp.inv_strip_w, y, xs);
+                uint32_t x = rp.x0 + xs;
+                pixel = x + y * rp.width;
+                key = path_key(rp.seed, (uint64_t)pixel, rp.first_sample + sample);
+                Rng g{key, 0};
+                ray = camera_ray(sv, x, y, rp.width, rp.height, g);
+                thr = {1.f, 1.f, 1.f};
+                seg = 0;
             }
         }
+        REGION_END(st, ST_REGEN, regen);
         const bool live = seg >= 0;
         if (WAVE && !__any(live)) break;
         Rng g{key, (uint32_t)(live ? seg : 0)};
         F3 radiance;
-        bool cont = path_segment<WAVE, FEAT>(sv, ray, thr, g, live, radiance, rays, light_queries);
+        bool cont = path_segment<WAVE, FEAT>(sv, ray, thr, g, live, radiance, rays, light_queries, st);
+        REGION_BEGIN(acc);
         if (live) {
             seg++;
             if (cont && seg >= 50) cont = false;  // depth 50 -> 0 returns BLACK (ray_tracer.rs:166-172, :451)
@@ -1409,8 +1481,14 @@ __global__ void __launch_bounds__(BLOCK, SEG_WAVES_PER_SIMD) k_segments(SceneVie
                 seg = -1;
             }
         }
-        if (!__any(seg >= 0 || (in_range && !exhausted))) break;
+        REGION_END(st, ST_ACCUM, acc);
+        if (!__any(seg >= 0) && dry && chunk_next >= chunk_end) break;
     }
+    REGION_END(st, ST_TOTAL, total);
+#ifdef MRT_STAMPS
+    for (int i = 0; i < ST_COUNT; ++i)
+        if (st.acc[i]) atomicAdd(&ctr->stamps[i], st.acc[i]);
+#endif
     if (in_range) {
         pool.seg[slot] = seg;
         if (seg >= 0) {
@@ -1426,15 +1504,19 @@ __global__ void __launch_bounds__(BLOCK, SEG_WAVES_PER_SIMD) k_segments(SceneVie
     rays = wave_sum(rays);
     light_queries = wave_sum(light_queries);
     if (lane_id() == 0) {
+        wave_chunks[2 * (size_t)wave_id] = chunk_next;
+        wave_chunks[2 * (size_t)wave_id + 1] = chunk_end;
+        if (chunk_end > chunk_next) atomicAdd(&ctr->held, chunk_end - chunk_next);
         if (live) atomicAdd(&ctr->live, live);
         if (rays) atomicAdd(&ctr->rays, (unsigned long long)rays);
         if (light_queries) atomicAdd(&ctr->light_queries, (unsigned long long)light_queries);
     }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_init_pool(Pool pool, uint32_t n) {
+__global__ void __launch_bounds__(BLOCK) k_init_pool(Pool pool, uint32_t n, unsigned long long* wave_chunks) {
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i < n) pool.seg[i] = -1;
+    if (i < n && (i & 63) == 0) wave_chunks[2 * (size_t)(i >> 6)] = 0, wave_chunks[2 * (size_t)(i >> 6) + 1] = 0;
 }
 
 // Stream compaction: live slots of `src` are packed to the front of `dst`
@@ -1485,13 +1567,14 @@ __global__ void __launch_bounds__(BLOCK) k_trace_rays(SceneView sv, const double
     }
     Rng g{path_key(seed, (uint64_t)i, 0), 0};
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
-    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g, live, h) : (live && nearest_hit_lane<FEAT>(sv, ray, g, h));
+    Stamps st{};
+    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g, live, h, st) : (live && nearest_hit_lane<FEAT>(sv, ray, g, h));
     if (!live) return;
     D3 n_w{0, 0, 0}, p_w{0, 0, 0};
     if (hit) {
-        const DObject* ob = sv.objects + h.obj;
+        const DObjRec* ob = sv.objects + h.obj;
         Surface s;
-        surface_at<FEAT>(ob, sv.shapes, ray, h.t, h.sub, h.pos, s);
+        surface_at<FEAT>(ob, ray, h.t, h.sub, h.pos, s);
         n_w = normal_to_world(ob, s.n_obj);
         p_w = point_to_world(ob, s.pos_obj);
     }
@@ -1560,6 +1643,7 @@ struct mrt_scene {
     std::unique_ptr<DeviceBuffers> pool_mem;
     Pool pool[2]{};
     Counters* counters = nullptr;
+    unsigned long long* wave_chunks = nullptr;  // [next, end) of the work range each wave holds
     uint32_t pool_slots = 0;
     // options
     int64_t opt_pool_slots = 1 << 21;
@@ -1620,7 +1704,7 @@ int upload_scene(mrt_scene* sc) {
     UP(f.bmin[0], bmin_x) UP(f.bmin[1], bmin_y) UP(f.bmin[2], bmin_z)
     UP(f.bmax[0], bmax_x) UP(f.bmax[1], bmax_y) UP(f.bmax[2], bmax_z)
     UP(f.node_object, node_object) UP(f.node_skip, node_skip) UP(f.node_flags, node_flags) UP(f.node_recs, node_recs)
-    UP(f.objects, objects) UP(f.lights, lights) UP(f.shapes, shapes) UP(f.materials, materials)
+    UP(f.obj_recs, objects) UP(f.light_recs, lights)
     UP(f.textures, textures) UP(f.images, images) UP(f.image_pool, image_pool)
     UP(f.octrees, octrees) UP(f.oct_nodes, oct_nodes) UP(f.oct_voxels, oct_voxels)
 #undef UP
@@ -1654,6 +1738,7 @@ int ensure_pool(mrt_scene* sc) {
         if ((rc = m.alloc(sizeof(int32_t) * want, reinterpret_cast<void**>(&p.seg))) != MRT_OK) return rc;
     }
     if ((rc = m.alloc(sizeof(Counters), reinterpret_cast<void**>(&sc->counters))) != MRT_OK) return rc;
+    if ((rc = m.alloc(sizeof(unsigned long long) * 2 * (want / 64), reinterpret_cast<void**>(&sc->wave_chunks))) != MRT_OK) return rc;
     sc->pool_slots = want;
     return MRT_OK;
 }
@@ -1679,6 +1764,9 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     rp.width = width, rp.height = height, rp.x0 = x0, rp.strip_w = strip_w;
     rp.npix_strip = (unsigned long long)strip_w * height;
     rp.n_work = rp.npix_strip * spp;
+    if (rp.n_work >= (1ull << 53)) return set_error(MRT_ERR_INVALID_ARGUMENT, "more than 2^53 paths in one call");
+    rp.inv_npix_strip = 1.0 / (double)rp.npix_strip;
+    rp.inv_strip_w = 1.0 / (double)strip_w;
     rp.seed = seed, rp.first_sample = first_sample;
     rp.steps = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(sc->opt_steps, 64));
     uint32_t n_slots = (uint32_t)std::min<unsigned long long>(sc->pool_slots, (rp.n_work + BLOCK - 1) / BLOCK * BLOCK);
@@ -1701,7 +1789,7 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     HIP_TRY(hipEventRecord(ev_begin, stream));
     HIP_TRY(hipMemsetAsync(sc->counters, 0, sizeof(Counters), stream));
     int cur = 0;
-    hipLaunchKernelGGL(k_init_pool, dim3(n_slots / BLOCK), dim3(BLOCK), 0, stream, sc->pool[cur], n_slots);
+    hipLaunchKernelGGL(k_init_pool, dim3(n_slots / BLOCK), dim3(BLOCK), 0, stream, sc->pool[cur], n_slots, sc->wave_chunks);
     HIP_TRY(hipGetLastError());
 
     Counters host{};
@@ -1709,7 +1797,7 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     uint64_t launches = 0;
     uint32_t active = n_slots;
     for (;;) {
-        HIP_TRY(hipMemsetAsync(&sc->counters->live, 0, sizeof(unsigned int) * 2, stream));
+        HIP_TRY(hipMemsetAsync(&sc->counters->live, 0, sizeof(unsigned int) * 2 + sizeof(unsigned long long), stream));
         rp.n_slots = active;
         HIP_TRY(hipEventRecord(ek0, stream));
         {
@@ -1717,9 +1805,9 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
             dispatch_feat(sc->features, KernelFeats{}, [&](auto feat) {
                 constexpr int FT = decltype(feat)::value;
                 if (wave_sync)
-                    hipLaunchKernelGGL((k_segments<true, FT>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
+                    hipLaunchKernelGGL((k_segments<true, FT>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters, sc->wave_chunks);
                 else
-                    hipLaunchKernelGGL((k_segments<false, FT>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters);
+                    hipLaunchKernelGGL((k_segments<false, FT>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters, sc->wave_chunks);
             });
         }
         HIP_TRY(hipGetLastError());
@@ -1730,7 +1818,7 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
         HIP_TRY(hipEventElapsedTime(&ms, ek0, ek1));
         kernel_ms += ms;
         launches++;
-        bool work_left = host.work_next < rp.n_work;
+        bool work_left = host.work_next < rp.n_work || host.held > 0;
         if (!work_left && host.live == 0) break;
         if (!work_left && sc->opt_compact && host.live * 4ull < (unsigned long long)active * 3ull && active > BLOCK) {
             // drain phase: pack the survivors so that later launches cover only live paths
@@ -1750,6 +1838,16 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     HIP_TRY(hipStreamSynchronize(stream));
     float total_ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&total_ms, ev_begin, ev_end));
+#ifdef MRT_STAMPS
+    {
+        static const char* names[ST_COUNT] = {"regen", "traverse(all)", "  leaf:solid", "surface+texture", "lambert:generate",
+                                              "lambert:light value", "shade(all)", "accumulate", "total", "  leaf:medium", "  regen:claim"};
+        std::fprintf(stderr, "[stamps] wave-cycles per region (share of total)\n");
+        for (int i = 0; i < ST_COUNT; ++i)
+            std::fprintf(stderr, "[stamps] %-22s %14llu  %5.1f%%\n", names[i], host.stamps[i],
+                         100.0 * (double)host.stamps[i] / (double)std::max(1ull, host.stamps[ST_TOTAL]));
+    }
+#endif
     if (stats) {
         stats->paths = rp.n_work;
         stats->rays = host.rays;

@@ -453,6 +453,32 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
             return fail(err, MRT_ERR_UNSUPPORTED, "light: MovingSphere / octree lights panic in the reference");
     }
 
+    // per-object / per-light records for the device
+    auto mk_rec = [&](const DObject& ob) {
+        DObjRec r;
+        std::memset(&r, 0, sizeof(r));
+        const DShape& sh = s.shapes[(size_t)ob.shape];
+        const DShape& geo = sh.kind == MRT_SHAPE_CONSTANT_MEDIUM ? s.shapes[(size_t)sh.boundary] : sh;
+        r.kind = sh.kind, r.gkind = geo.kind, r.identity = ob.identity, r.octree = sh.octree;
+        std::memcpy(r.p, geo.p, sizeof(r.p));
+        if (sh.kind == MRT_SHAPE_CONSTANT_MEDIUM) r.p[9] = sh.p[9];
+        r.texture = -1;
+        if (sh.kind != MRT_SHAPE_OCTREE) {
+            const DMaterial& m = s.materials[(size_t)sh.material];
+            r.mat_kind = m.kind, r.texture = m.texture, r.fuzz = m.fuzz, r.index_refraction = m.index_refraction;
+            std::memcpy(r.color, m.color, sizeof(r.color));
+            if (m.kind != MRT_MAT_DIELECTRIC && m.texture >= 0 && s.textures[(size_t)m.texture].kind == MRT_TEX_SOLID) {
+                r.tex_solid = 1;
+                std::memcpy(r.color, s.textures[(size_t)m.texture].color, sizeof(r.color));
+            }
+        }
+        r.to_object = ob.to_object, r.to_world = ob.to_world;
+        std::memcpy(r.normal_m, ob.normal_m, sizeof(r.normal_m));
+        return r;
+    };
+    for (const DObject& ob : s.objects) s.obj_recs.push_back(mk_rec(ob));
+    for (const DObject& ob : s.lights) s.light_recs.push_back(mk_rec(ob));
+
     // Camera::new (camera.rs:44-76)
     {
         const mrt_camera_info& ci = d->camera;

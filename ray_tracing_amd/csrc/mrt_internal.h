@@ -98,6 +98,30 @@ struct DNodeRec {
 };
 static_assert(sizeof(DNodeRec) == 256, "DNodeRec must be 256 bytes");
 
+// One self-contained record per object (and per light) for everything that is indexed per lane:
+// the leaf test of the per-lane walk, the surface data at a hit, the material response and the
+// light sampling. One record means one batch of independent loads instead of the dependent chain
+// object -> shape -> (boundary) -> material -> texture.
+struct DObjRec {
+    int32_t kind;       // shape kind of the object (CONSTANT_MEDIUM for media)
+    int32_t gkind;      // kind of the geometry: the boundary's for media, else `kind`
+    int32_t identity;   // object transform is the identity
+    int32_t octree;     // octree index for OCTREE shapes
+    int32_t mat_kind;   // material kind (phase function for media); unused for OCTREE
+    int32_t texture;    // texture index of the material
+    int32_t tex_solid;  // 1: the texture is a SolidColor and `color` holds its value
+    int32_t pad;
+    float color[3];     // SolidColor value, or the Dielectric colour
+    int32_t pad2;
+    double fuzz, index_refraction;
+    double p[10];       // geometry parameters (media: the boundary's, and p[9] = -1/density)
+    Affine to_object;   // world_transform
+    Affine to_world;    // world_transform^-1
+    double normal_m[3][3];
+    double pad3;
+};
+static_assert(sizeof(DObjRec) == 416, "DObjRec layout");
+
 // Host-side flattened scene.
 struct FlatScene {
     std::vector<DObject> objects, lights;
@@ -119,6 +143,7 @@ struct FlatScene {
     std::vector<double> bmin[3], bmax[3];
     std::vector<int32_t> node_object, node_skip, node_flags;
     std::vector<DNodeRec> node_recs;
+    std::vector<DObjRec> obj_recs, light_recs;
     bool has_medium = false;
 };
 
