@@ -40,7 +40,8 @@ struct SceneView {
     const int32_t* node_object;
     const int32_t* node_skip;
     const int32_t* node_flags;
-    const DNodeRec* node_recs;
+    const DNodeRec* node_recs;  // what the wave-synchronous walk visits: the tree, or its leaf list
+    int32_t n_wave_nodes;
     int32_t n_nodes;
     int32_t n_objects;
     int32_t n_lights;
@@ -178,7 +179,8 @@ __device__ __forceinline__ double rsqrt_fast(double x) {
 // cgmath normalize: self * (1 / magnitude)
 __device__ __forceinline__ D3 normalize(D3 a) {
     double d2 = dot(a, a);
-    double inv = (d2 > 1e-300 && d2 < 1e300) ? rsqrt_fast(d2) : 1.0 / sqrt(d2);
+    double inv = rsqrt_fast(d2);
+    if (__builtin_expect(!(d2 > 1e-300 && d2 < 1e300), 0)) inv = 1.0 / sqrt(d2);  // zero, huge, NaN: IEEE path
     return a * inv;
 }
 constexpr double INV_PI = 0.31830988618379067154;
@@ -315,6 +317,49 @@ __device__ __forceinline__ bool box_hit(PP p, const RayD& r, D3 inv, double t_mi
     t_out = best;
     face = f;
     return any;
+}
+
+// The two boundary queries of a medium around a RenderBox (constant_medium.rs:36-44): nearest face
+// hit in [-1e10, 1e10], then nearest in [t1 + 1e-4, 1e10]. Whether a plane's intersection point
+// lies inside its face does not depend on the query range, so both queries share the six plane
+// intersections; the selection keeps box_hit's order and "strictly smaller replaces" rule.
+template <int AXIS>
+__device__ __forceinline__ void rect_plane(double a0, double a1, double b0, double b1, double k, const RayD& r, D3 inv,
+                                           double& t, bool& inside) {
+    constexpr int IA = AXIS == 0 ? 1 : 0;
+    constexpr int IB = AXIS == 2 ? 1 : 2;
+    t = (k - comp(r.o, AXIS)) * comp(inv, AXIS);
+    double a = comp(r.o, IA) + t * comp(r.d, IA);
+    double b = comp(r.o, IB) + t * comp(r.d, IB);
+    inside = !(a < a0 || a > a1 || b < b0 || b > b1);
+}
+template <class PP>
+__device__ __forceinline__ bool box_hit_twice(PP p, const RayD& r, D3 inv, double& t1, double& t2) {
+    double tf[6];
+    bool in[6];
+    rect_plane<2>(p[0], p[3], p[1], p[4], p[5], r, inv, tf[0], in[0]);
+    rect_plane<2>(p[0], p[3], p[1], p[4], p[2], r, inv, tf[1], in[1]);
+    rect_plane<1>(p[0], p[3], p[2], p[5], p[4], r, inv, tf[2], in[2]);
+    rect_plane<1>(p[0], p[3], p[2], p[5], p[1], r, inv, tf[3], in[3]);
+    rect_plane<0>(p[1], p[4], p[2], p[5], p[3], r, inv, tf[4], in[4]);
+    rect_plane<0>(p[1], p[4], p[2], p[5], p[0], r, inv, tf[5], in[5]);
+    double lo = -10000000000.0;
+    const double hi = 10000000000.0;
+    double best[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        bool any = false;
+        double b = 0.0;
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            if (in[f] && !(tf[f] < lo || tf[f] > hi) && (!any || tf[f] < b)) any = true, b = tf[f];
+        }
+        if (!any) return false;
+        best[q] = b;
+        lo = b + 0.0001;
+    }
+    t1 = best[0], t2 = best[1];
+    return true;
 }
 
 // Deterministic shapes (everything a ConstantMedium may wrap). `sub` = box face.
@@ -575,7 +620,13 @@ __device__ __forceinline__ bool leaf_hit(const SceneView& sv, int kind, int bkin
     const double hi = medium ? 10000000000.0 : t_max;
     double t1 = 0.0, t2 = 0.0;
     int s1 = 0;
-    const int rounds = medium ? 2 : 1;
+    int rounds = medium ? 2 : 1;
+    if constexpr ((FEAT & FEAT_MEDIUM) != 0) {
+        if (medium && bkind == MRT_SHAPE_RENDER_BOX) {
+            if (!box_hit_twice(p, sr, inv, t1, t2)) return false;
+            rounds = 0;
+        }
+    }
 #pragma nounroll
     for (int c = 0; c < rounds; ++c) {
         double th;
@@ -710,7 +761,7 @@ __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng
     D3 best_pos{0.0, 0.0, 0.0};
     uint32_t medium_ordinal = 0;
     D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
-    const int n = sv.n_nodes;
+    const int n = sv.n_wave_nodes;
     auto recs = as_const(sv.node_recs);
     int resume = live ? 0 : n;
     int i = 0;
@@ -1130,7 +1181,8 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
         own = c <= 0.0 ? 0.0 : c * INV_PI;
     } else if (r == 1) {  // LightPdf::generate, pdf.rs:104-130
         if (sv.n_lights == 0) return false;
-        uint32_t idx = rand_u32(g, 0, (uint32_t)sv.n_lights, MRT_DIM_LIGHT_INDEX);
+        // a one-entry list needs no draw (x % 1 == 0; draws are addressed by dimension)
+        uint32_t idx = sv.n_lights == 1 ? 0u : rand_u32(g, 0, (uint32_t)sv.n_lights, MRT_DIM_LIGHT_INDEX);
         AreaInfo ai;
         object_generate<(FEAT & ~FEAT_OCTREE)>(sv.lights + idx, hit_point, incoming_time, g, ai);
         D3 nd = normalize(ai.to_area.d);
@@ -1647,10 +1699,12 @@ struct mrt_scene {
     uint32_t pool_slots = 0;
     // options
     int64_t opt_pool_slots = 1 << 21;
-    int64_t opt_steps = 16;
+    int64_t opt_steps = 32;
     int64_t opt_trace_zero = 0;
     int64_t opt_compact = 1;
-    int64_t opt_traversal = 0;  // 0 auto, 1 per-lane, 2 wave-synchronous
+    int64_t opt_traversal = 0;  // 0 auto, 1 per-lane, 2 wave-synchronous over the tree, 3 over the leaf list
+    const DNodeRec* dev_node_recs = nullptr;
+    const DNodeRec* dev_leaf_recs = nullptr;
     int features = 0;           // FEAT_* bits the scene needs
     std::mutex mu;
 };
@@ -1684,12 +1738,29 @@ static int scene_features(const FlatScene& f) {
     return need;
 }
 
-// Trees of at most this many nodes are walked wave-synchronously.
+// Trees of at most WAVE_SYNC_MAX_NODES nodes are walked wave-synchronously; with at most
+// LEAF_LIST_MAX leaves the walk visits the leaf list instead of the tree.
 constexpr int WAVE_SYNC_MAX_NODES = 64;
-static bool use_wave_sync(const mrt_scene* sc) {
-    if (sc->opt_traversal == 1) return false;
-    if (sc->opt_traversal == 2) return true;
-    return (int)sc->flat.node_object.size() <= WAVE_SYNC_MAX_NODES;
+constexpr int LEAF_LIST_MAX = 16;
+enum : int { TRAV_LANE = 1, TRAV_WAVE_TREE = 2, TRAV_WAVE_LEAVES = 3 };
+static int traversal_mode(const mrt_scene* sc) {
+    const bool have_list = !sc->flat.leaf_recs.empty();
+    if (sc->opt_traversal == TRAV_LANE || sc->opt_traversal == TRAV_WAVE_TREE) return (int)sc->opt_traversal;
+    if (sc->opt_traversal == TRAV_WAVE_LEAVES) return have_list ? TRAV_WAVE_LEAVES : TRAV_WAVE_TREE;
+    if ((int)sc->flat.node_object.size() > WAVE_SYNC_MAX_NODES) return TRAV_LANE;
+    return have_list && (int)sc->flat.leaf_recs.size() <= LEAF_LIST_MAX ? TRAV_WAVE_LEAVES : TRAV_WAVE_TREE;
+}
+// Scene view for one launch: points the wave-synchronous walk at the tree or at the leaf list.
+static SceneView view_for(const mrt_scene* sc, int mode) {
+    SceneView v = sc->view;
+    if (mode == TRAV_WAVE_LEAVES) {
+        v.node_recs = sc->dev_leaf_recs;
+        v.n_wave_nodes = (int32_t)sc->flat.leaf_recs.size();
+    } else {
+        v.node_recs = sc->dev_node_recs;
+        v.n_wave_nodes = (int32_t)sc->flat.node_recs.size();
+    }
+    return v;
 }
 
 namespace {
@@ -1703,7 +1774,9 @@ int upload_scene(mrt_scene* sc) {
     if ((rc = m.upload(vec, &v.field)) != MRT_OK) return rc;
     UP(f.bmin[0], bmin_x) UP(f.bmin[1], bmin_y) UP(f.bmin[2], bmin_z)
     UP(f.bmax[0], bmax_x) UP(f.bmax[1], bmax_y) UP(f.bmax[2], bmax_z)
-    UP(f.node_object, node_object) UP(f.node_skip, node_skip) UP(f.node_flags, node_flags) UP(f.node_recs, node_recs)
+    UP(f.node_object, node_object) UP(f.node_skip, node_skip) UP(f.node_flags, node_flags)
+    if ((rc = m.upload(f.node_recs, &sc->dev_node_recs)) != MRT_OK) return rc;
+    if ((rc = m.upload(f.leaf_recs, &sc->dev_leaf_recs)) != MRT_OK) return rc;
     UP(f.obj_recs, objects) UP(f.light_recs, lights)
     UP(f.textures, textures) UP(f.images, images) UP(f.image_pool, image_pool)
     UP(f.octrees, octrees) UP(f.oct_nodes, oct_nodes) UP(f.oct_voxels, oct_voxels)
@@ -1770,9 +1843,10 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     rp.seed = seed, rp.first_sample = first_sample;
     rp.steps = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(sc->opt_steps, 64));
     uint32_t n_slots = (uint32_t)std::min<unsigned long long>(sc->pool_slots, (rp.n_work + BLOCK - 1) / BLOCK * BLOCK);
-    SceneView view = sc->view;
+    const int trav = traversal_mode(sc);
+    SceneView view = view_for(sc, trav);
     view.trace_zero_throughput = (int32_t)sc->opt_trace_zero;
-    const bool wave_sync = use_wave_sync(sc);
+    const bool wave_sync = trav != TRAV_LANE;
 
     hipEvent_t ev_begin, ev_end, ek0, ek1;
     HIP_TRY(hipEventCreate(&ev_begin));
@@ -1952,7 +2026,7 @@ int mrt_scene_set_option(mrt_scene* scene, const char* name, int64_t value) {
     } else if (n == "compaction") {
         scene->opt_compact = value ? 1 : 0;
     } else if (n == "traversal") {
-        if (value < 0 || value > 2) return set_error(MRT_ERR_INVALID_ARGUMENT, "traversal must be 0, 1 or 2");
+        if (value < 0 || value > 3) return set_error(MRT_ERR_INVALID_ARGUMENT, "traversal must be 0..3");
         scene->opt_traversal = value;
     } else {
         return set_error(MRT_ERR_INVALID_ARGUMENT, "unknown option: " + n);
@@ -2007,13 +2081,15 @@ int mrt_trace_rays(mrt_scene* scene, const double* rays, size_t n, uint64_t seed
     HIP_TRY(hipMemcpy(drays, rays, sizeof(double) * 7 * n, hipMemcpyHostToDevice));
     {
         const dim3 grid(((uint32_t)n + BLOCK - 1) / BLOCK), block(BLOCK);
-        const bool ws = use_wave_sync(scene);
+        const int trav = traversal_mode(scene);
+        const bool ws = trav != TRAV_LANE;
+        const SceneView view = view_for(scene, trav);
         dispatch_feat(scene->features, KernelFeats{}, [&](auto feat) {
             constexpr int FT = decltype(feat)::value;
             if (ws)
-                hipLaunchKernelGGL((k_trace_rays<true, FT>), grid, block, 0, 0, scene->view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
+                hipLaunchKernelGGL((k_trace_rays<true, FT>), grid, block, 0, 0, view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
             else
-                hipLaunchKernelGGL((k_trace_rays<false, FT>), grid, block, 0, 0, scene->view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
+                hipLaunchKernelGGL((k_trace_rays<false, FT>), grid, block, 0, 0, view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
         });
     }
     HIP_TRY(hipGetLastError());

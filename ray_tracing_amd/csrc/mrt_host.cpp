@@ -568,6 +568,15 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
                 }
             }
         }
+        bool dynamic = false;
+        for (const DNodeRec& r : s.node_recs) dynamic = dynamic || (r.flags & NODE_DYNAMIC_BOX);
+        if (!dynamic) {
+            for (const DNodeRec& r : s.node_recs)
+                if (r.object >= 0) {
+                    s.leaf_recs.push_back(r);
+                    s.leaf_recs.back().skip = (int32_t)s.leaf_recs.size();
+                }
+        }
     }
     return MRT_OK;
 }

@@ -143,6 +143,12 @@ struct FlatScene {
     std::vector<double> bmin[3], bmax[3];
     std::vector<int32_t> node_object, node_skip, node_flags;
     std::vector<DNodeRec> node_recs;
+    // The leaves of node_recs in the same (pre-)order, each linked to the next one. A leaf's box lies
+    // inside the boxes of its ancestors, so an ancestor's test can only reject rays the leaf's own box
+    // rejects too: walking this list gives the results of the tree walk without the inner-node tests,
+    // which is cheaper when the rays that share the walk (a wave) have nothing in common.
+    // Empty when a leaf box depends on the query (NODE_DYNAMIC_BOX).
+    std::vector<DNodeRec> leaf_recs;
     std::vector<DObjRec> obj_recs, light_recs;
     bool has_medium = false;
 };

@@ -192,7 +192,7 @@ def test_early_termination_does_not_change_the_image(worlds):
 
 @pytest.mark.parametrize("opts", [dict(pool_slots=256, segments_per_launch=1), dict(pool_slots=4096, segments_per_launch=7),
                                   dict(pool_slots=1 << 20, segments_per_launch=50), dict(compaction=0),
-                                  dict(traversal=1), dict(traversal=2)])
+                                  dict(traversal=1), dict(traversal=2), dict(traversal=3)])
 def test_scheduling_options_do_not_change_results(opts):
     """Pool size / segments per launch / compaction only change the order of work."""
     info = scenarios.cornell_smoke()
