@@ -39,6 +39,26 @@ def cpu_baseline(info, width, height, spp, threads):
                       f"(threaded_render layout)"}
 
 
+def pmc_traffic(workload, launches_per_step):
+    """HBM bytes per segment-kernel launch from the committed rocprofv3 counter passes
+    (profiles/*_pmc_traffic.json, written by scripts/pmc_traffic.py), or None when no pass of this
+    workload with the same launch count per step is on file. Counters cannot be read from inside
+    the timed run, so the value is that of the profiled run of this same command."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(f))
+            line = d.get("bench_line_under_trace", {})
+            same = line.get("config", {}).get("workload") == workload
+            per_step = line.get("roofline", {}).get("launches", 0) / max(1, line.get("steps", 1))
+            if same and abs(per_step - launches_per_step) <= 1 and "hbm_bytes_per_launch" in d:
+                best = float(d["hbm_bytes_per_launch"])
+        except (OSError, ValueError):
+            continue
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,6 +145,7 @@ def main():
         kernel_s = totals["kernel_ms"] / 1e3
         algo_bytes = B_SEG * totals["rays"] + B_PATH * totals["paths"]   # this rank's segment kernels
         achieved = algo_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
+        workload = f"cornell_smoke {W}x{H} @ {spp} spp per GPU, depth 50, seed 0"
         out = {
             "metric": "Mpaths/s, Cornell smoke 1920x1080",
             "value": all_paths / elapsed / 1e6,
@@ -138,14 +159,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"cornell_smoke {W}x{H} @ {spp} spp per GPU, depth 50, seed 0",
+            "config": {"workload": workload,
                        "parallelism": f"spp-split x{world_size} + one all-reduce of the f32 accumulation buffer"},
             "mrays_per_s": all_rays / elapsed / 1e6,
             "light_queries_per_s_M": all_lq / elapsed / 1e6,
             "segments_per_path": all_rays / all_paths if all_paths else 0.0,
             "mean_radiance": mean,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(workload, totals["launches"] / max(1, args.steps)),
                          "kernel": "k_segments", "avg_launch_ms": totals["kernel_ms"] / max(1, totals["launches"]),
                          "launches": totals["launches"],
                          "algorithmic_bytes_per_launch": algo_bytes / max(1, totals["launches"])},

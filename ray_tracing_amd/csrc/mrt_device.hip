@@ -31,15 +31,7 @@ namespace mrt {
 
 // ============================================================== device-side views
 struct SceneView {
-    const double* bmin_x;
-    const double* bmin_y;
-    const double* bmin_z;
-    const double* bmax_x;
-    const double* bmax_y;
-    const double* bmax_z;
-    const int32_t* node_object;
-    const int32_t* node_skip;
-    const int32_t* node_flags;
+    const DNode* nodes;  // the tree for the per-lane walk
     const DNodeRec* node_recs;  // what the wave-synchronous walk visits: the tree, or its leaf list
     int32_t n_wave_nodes;
     int32_t n_nodes;
@@ -711,15 +703,16 @@ __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng
     int i = 0;
     const int n = sv.n_nodes;
     while (i < n) {
-        const int obj = sv.node_object[i];
-        const int flags = sv.node_flags[i];
-        D3 mn{sv.bmin_x[i], sv.bmin_y[i], sv.bmin_z[i]};
-        D3 mx{sv.bmax_x[i], sv.bmax_y[i], sv.bmax_z[i]};
+        const DNode nd = sv.nodes[i];
+        const int obj = nd.object;
+        const int flags = nd.flags;
+        D3 mn{nd.bmin[0], nd.bmin[1], nd.bmin[2]};
+        D3 mx{nd.bmax[0], nd.bmax[1], nd.bmax[2]};
         if constexpr ((FEAT & FEAT_SPHERE) != 0) {
             if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(sv.objects + obj, t_min, closest, mn, mx);
         }
         if (!aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
-            i = sv.node_skip[i];
+            i = nd.skip;
             continue;
         }
         if (obj >= 0) {
@@ -1416,9 +1409,13 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
 
 // ============================================================== kernels
 constexpr int BLOCK = 256;
-#ifndef SEG_WAVES_PER_SIMD
-#define SEG_WAVES_PER_SIMD 2
-#endif
+// Waves per SIMD the segment kernel is compiled for (512 / waves registers per lane). Measured:
+// three waves hide the scene-record and pool latencies best as long as the kernel fits 168
+// registers without heavy spilling; the wave-synchronous kernels of the large feature sets
+// (specular materials, image / procedural textures) run faster with two.
+constexpr int seg_waves(bool wave, int feat) {
+    return (wave && (feat & (FEAT_SPECULAR | FEAT_TEXTURE)) != 0) ? 2 : 3;
+}
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -1428,7 +1425,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 // One launch = up to `steps` segments for every slot of the pool.
 template <bool WAVE, int FEAT>
-__global__ void __launch_bounds__(BLOCK, SEG_WAVES_PER_SIMD) k_segments(SceneView sv, Pool pool, RenderParams rp, Counters* ctr,
+__global__ void __launch_bounds__(BLOCK, seg_waves(WAVE, FEAT)) k_segments(SceneView sv, Pool pool, RenderParams rp, Counters* ctr,
                                                                      unsigned long long* wave_chunks) {
     const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
     const bool in_range = slot < rp.n_slots;
@@ -1712,7 +1709,8 @@ struct mrt_scene {
 // Feature sets the kernels are instantiated for, smallest first; the last one covers everything.
 template <int... M>
 struct FeatList {};
-using KernelFeats = FeatList<0, FEAT_MEDIUM, FEAT_SPHERE | FEAT_MEDIUM | FEAT_SPECULAR | FEAT_TEXTURE | FEAT_SKY,
+using KernelFeats = FeatList<0, FEAT_MEDIUM, FEAT_SPHERE | FEAT_MEDIUM, FEAT_SPHERE | FEAT_SPECULAR | FEAT_TEXTURE | FEAT_SKY,
+                             FEAT_SPHERE | FEAT_MEDIUM | FEAT_SPECULAR | FEAT_TEXTURE | FEAT_SKY,
                              FEAT_OCTREE | FEAT_SKY, FEAT_ALL>;
 // Calls f(std::integral_constant<int, M>) for the first instantiated set M that covers `need`.
 template <class F, int M0, int... M>
@@ -1772,9 +1770,7 @@ int upload_scene(mrt_scene* sc) {
     int rc;
 #define UP(vec, field)                                       \
     if ((rc = m.upload(vec, &v.field)) != MRT_OK) return rc;
-    UP(f.bmin[0], bmin_x) UP(f.bmin[1], bmin_y) UP(f.bmin[2], bmin_z)
-    UP(f.bmax[0], bmax_x) UP(f.bmax[1], bmax_y) UP(f.bmax[2], bmax_z)
-    UP(f.node_object, node_object) UP(f.node_skip, node_skip) UP(f.node_flags, node_flags)
+    UP(f.nodes, nodes)
     if ((rc = m.upload(f.node_recs, &sc->dev_node_recs)) != MRT_OK) return rc;
     if ((rc = m.upload(f.leaf_recs, &sc->dev_leaf_recs)) != MRT_OK) return rc;
     UP(f.obj_recs, objects) UP(f.light_recs, lights)

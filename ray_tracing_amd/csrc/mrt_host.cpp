@@ -541,6 +541,12 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
         auto root = b.build(order, 0);
         emit_full(root.get(), &s.bvh_full);
         emit_device(s, root.get(), &s);
+        s.nodes.resize(s.node_object.size());
+        for (size_t i = 0; i < s.nodes.size(); ++i) {
+            DNode& nd = s.nodes[i];
+            for (int a = 0; a < 3; ++a) nd.bmin[a] = s.bmin[a][i], nd.bmax[a] = s.bmax[a][i];
+            nd.object = s.node_object[i], nd.skip = s.node_skip[i], nd.flags = s.node_flags[i], nd.pad = 0;
+        }
         // self-contained node records for the wave-synchronous walk
         s.node_recs.resize(s.node_object.size());
         for (size_t i = 0; i < s.node_recs.size(); ++i) {

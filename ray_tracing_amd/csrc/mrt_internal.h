@@ -80,6 +80,16 @@ enum : int32_t {
     NODE_TWICE = 2         // span-1 leaf pair folded into one node; evaluate the object twice (bvh.rs:224-232)
 };
 
+// Device BVH node of the per-lane walk: one 64-byte line per node.
+struct DNode {
+    double bmin[3], bmax[3];
+    int32_t object;  // >= 0 leaf, -1 inner
+    int32_t skip;    // next node in pre-order when this subtree is left
+    int32_t flags;   // NODE_*
+    int32_t pad;
+};
+static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
+
 // One self-contained record per device BVH node for the wave-synchronous walk: everything the
 // box test and the leaf's intersection test need, so a node costs one batch of scalar loads
 // instead of the chain node -> object -> shape (-> boundary shape).
@@ -142,6 +152,7 @@ struct FlatScene {
     // device BVH: duplicate leaves folded; SoA
     std::vector<double> bmin[3], bmax[3];
     std::vector<int32_t> node_object, node_skip, node_flags;
+    std::vector<DNode> nodes;
     std::vector<DNodeRec> node_recs;
     // The leaves of node_recs in the same (pre-)order, each linked to the next one. A leaf's box lies
     // inside the boxes of its ancestors, so an ancestor's test can only reject rays the leaf's own box

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Summarises a scripts/profile_bench.sh output directory into one JSON file.
+
+HBM traffic of the segment kernel per launch from the FETCH_SIZE / WRITE_SIZE passes (both in
+KiB; on gfx950 FETCH_SIZE tallies 128-byte read requests as 64 bytes, so reads are doubled, which
+is an upper bound for the 8- and 4-byte-per-lane streams of the path pool), the kernel's average
+duration from the kernel trace, and lane utilisation / wait shares from the SQ pass.
+usage: pmc_traffic.py gpurun_out/prof_<tag> out.json
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def counters(pattern):
+    files = glob.glob(pattern)
+    if not files:
+        return {}, {}
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    for r in csv.DictReader(open(files[0])):
+        k = r["Kernel_Name"].split("(")[0]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
+    return agg, {k: len(v) for k, v in disp.items()}
+
+
+def main():
+    root, out = sys.argv[1], sys.argv[2]
+    res = {"source": root, "kernel": None}
+    stats = glob.glob(f"{root}/trace/*/*_kernel_stats.csv")
+    if stats:
+        for r in csv.DictReader(open(stats[0])):
+            if "k_segments" in r["Name"]:
+                res["kernel"] = r["Name"].split("(")[0]
+                res["trace"] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                                "total_ms": float(r["TotalDurationNs"]) / 1e6, "percent_of_gpu_time": float(r["Percentage"])}
+    for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        agg, n = counters(f"{root}/pmc_{name}/*/*_counter_collection.csv")
+        for k in agg:
+            if "k_segments" in k:
+                res[ctr] = {"launches": n[k], "kib_per_launch": agg[k][ctr] / n[k]}
+    if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
+        f, w = res["FETCH_SIZE"]["kib_per_launch"], res["WRITE_SIZE"]["kib_per_launch"]
+        res["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
+        res["hbm_bytes_per_launch_uncorrected"] = (f + w) * 1024.0
+    agg, n = counters(f"{root}/pmc_sq/*/*_counter_collection.csv")
+    for k, a in agg.items():
+        if "k_segments" in k and a.get("SQ_WAVE_CYCLES"):
+            wc = a["SQ_WAVE_CYCLES"]
+            res["sq"] = {"lane_utilisation": a["SQ_THREAD_CYCLES_VALU"] / (64.0 * a["SQ_ACTIVE_INST_VALU"]),
+                         "valu_active_per_wave_cycle": a["SQ_ACTIVE_INST_VALU"] / wc,
+                         "scalar_active_per_wave_cycle": a.get("SQ_ACTIVE_INST_SCA", 0.0) / wc,
+                         "wait_any_per_wave_cycle": a["SQ_WAIT_ANY"] / wc,
+                         "wait_inst_any_per_wave_cycle": a["SQ_WAIT_INST_ANY"] / wc}
+    for f in glob.glob(f"{root}/bench_trace.json"):
+        for line in open(f):
+            if line.startswith("{"):
+                res["bench_line_under_trace"] = json.loads(line)
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
