@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--pool-slots", type=int, default=0)
     ap.add_argument("--segments-per-launch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=8)
+    ap.add_argument("--cpu-spp", type=int, default=64)
     args = ap.parse_args()
 
     import torch

@@ -199,12 +199,15 @@ __host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 __host__ __device__ __forceinline__ uint64_t path_key(uint64_t seed, uint64_t pixel, uint64_t sample) {
     return mix64(mix64(seed + 0x9E3779B97F4A7C15ULL * (pixel + 1)) ^ (0xD1B54A32D192ED03ULL * (sample + 1)));
 }
+// u64(key, seg, dim) = mix64(key + G * (((seg << 16) | dim) + 1)) with dim < 2^16. The part that
+// depends on the segment, key + G * (seg << 16), is formed once per segment; a draw then adds the
+// constant G * (dim + 1) (a compile-time constant for nearly every dimension) and mixes.
 struct Rng {
-    uint64_t key;
-    uint32_t seg;
+    uint64_t base;
+    __device__ __forceinline__ Rng(uint64_t key, uint32_t seg) : base(key + 0x9E3779B97F4A7C15ULL * ((uint64_t)seg << 16)) {}
 };
 __device__ __forceinline__ uint64_t rng_u64(const Rng& g, uint32_t dim) {
-    return mix64(g.key + 0x9E3779B97F4A7C15ULL * ((((uint64_t)g.seg << 16) | dim) + 1));
+    return mix64(g.base + 0x9E3779B97F4A7C15ULL * (uint64_t)(dim + 1));
 }
 __device__ __forceinline__ double rng_f64(const Rng& g, uint32_t dim) {
     return (double)(rng_u64(g, dim) >> 11) * 0x1.0p-53;
