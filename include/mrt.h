@@ -297,8 +297,17 @@ int mrt_render_accumulate_device(mrt_scene* scene, float* accum_rgb_device, uint
 int mrt_to_image(const float* accum_rgb, uint32_t width, uint32_t height, uint32_t num_samples,
                  uint8_t* rgb8_out);
 
-/* Tuning knobs (performance only, never results): "pool_slots",
- * "segments_per_launch". Returns MRT_ERR_INVALID_ARGUMENT for unknown names. */
+/* Tuning knobs (performance only; results change at most in the order of the
+ * f32 accumulation adds, except "trace_zero_throughput"):
+ *   "pool_slots"             path slots in flight (default 2^21)
+ *   "segments_per_launch"    1..64 segments per kernel launch (default 32)
+ *   "compaction"             0/1 pack live paths in the drain phase (default 1)
+ *   "traversal"              0 auto, 1 per-lane tree walk, 2 wave-synchronous
+ *                            tree walk, 3 wave-synchronous walk over the leaf list
+ *   "trace_zero_throughput"  1: keep walking paths whose throughput is exactly
+ *                            zero, as the reference does (same image, counters
+ *                            match the reference's)
+ * Returns MRT_ERR_INVALID_ARGUMENT for unknown names or values out of range. */
 int mrt_scene_set_option(mrt_scene* scene, const char* name, int64_t value);
 
 /* ------------------------------------------------- random number contract
