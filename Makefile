@@ -14,19 +14,20 @@ all: lib oracle
 
 lib: $(LIB)
 
-$(LIB): $(CSRC)/mrt_device.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_internal.h include/mrt.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/mrt_device.hip $(CSRC)/mrt_host.cpp
+$(LIB): $(CSRC)/mrt_device.hip $(CSRC)/mrt_post.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_internal.h include/mrt.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/mrt_device.hip $(CSRC)/mrt_post.hip $(CSRC)/mrt_host.cpp
 
 # Diagnostic build: in-kernel cycle stamps per region of the segment kernel (never benchmarked).
 stamps: ray_tracing_amd/libmrt_stamps.so
-ray_tracing_amd/libmrt_stamps.so: $(CSRC)/mrt_device.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_internal.h include/mrt.h
-	$(HIPCC) $(HIPFLAGS) -DMRT_STAMPS -shared -o $@ $(CSRC)/mrt_device.hip $(CSRC)/mrt_host.cpp
+ray_tracing_amd/libmrt_stamps.so: $(CSRC)/mrt_device.hip $(CSRC)/mrt_post.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_internal.h include/mrt.h
+	$(HIPCC) $(HIPFLAGS) -DMRT_STAMPS -shared -o $@ $(CSRC)/mrt_device.hip $(CSRC)/mrt_post.hip $(CSRC)/mrt_host.cpp
 
 oracle: $(ORACLE)
 
 # -march=native is deliberately NOT used: the .so is built here and run on the GPU box's host.
-$(ORACLE): oracle/cpu_ref.cpp oracle/octree_api.cpp oracle/octree_ref.h include/mrt.h
-	$(CXX) $(CXXFLAGS) -shared -pthread -o $@ oracle/cpu_ref.cpp oracle/octree_api.cpp
+# -ffp-contract=off: the f32 image arithmetic of post_ref.cpp must round after every operation.
+$(ORACLE): oracle/cpu_ref.cpp oracle/octree_api.cpp oracle/post_ref.cpp oracle/octree_ref.h include/mrt.h
+	$(CXX) $(CXXFLAGS) -ffp-contract=off -shared -pthread -o $@ oracle/cpu_ref.cpp oracle/octree_api.cpp oracle/post_ref.cpp
 
 clean:
 	rm -f $(LIB) $(ORACLE)

@@ -297,6 +297,24 @@ int mrt_render_accumulate_device(mrt_scene* scene, float* accum_rgb_device, uint
 int mrt_to_image(const float* accum_rgb, uint32_t width, uint32_t height, uint32_t num_samples,
                  uint8_t* rgb8_out);
 
+/* Post-processing step of `RayTracer::tracing_loop` (ray_tracer.rs:473-476,
+ * :465-467): out = bloom(accum / num_samples), bloom = ray_tracer/bloom.rs:75-94
+ * (bright-pass, 7-level 9-tap blur pyramid with the bilinear up-add of
+ * parallel_image.rs:193-260, tone map 1 - exp(-hdr*(bloom+hdr)), pow(1/2.2)).
+ * Images are float[height][width][3] like the accumulation buffer; `out` may
+ * not alias `accum`. The image must be at least 128x128 (below that the
+ * reference panics in get_nearest; MRT_ERR_UNSUPPORTED). Device-resident
+ * buffers on `device`; `stream` is a hipStream_t (NULL = default stream); the
+ * call returns after the work has completed. */
+int mrt_bloom_device(int device, const float* accum_rgb_device, uint32_t width, uint32_t height,
+                     uint32_t num_samples, float* out_rgb_device, void* stream);
+/* Same with host buffers (uploaded to `device`, processed there, downloaded). */
+int mrt_bloom(int device, const float* accum_rgb, uint32_t width, uint32_t height,
+              uint32_t num_samples, float* out_rgb);
+/* mrt_to_image on device-resident buffers (parallel_image.rs:35-65). */
+int mrt_to_image_device(int device, const float* rgb_device, uint32_t width, uint32_t height,
+                        uint32_t num_samples, uint8_t* rgb8_out_device, void* stream);
+
 /* Tuning knobs (performance only; results change at most in the order of the
  * f32 accumulation adds, except "trace_zero_throughput"):
  *   "pool_slots"             path slots in flight (default 2^21)

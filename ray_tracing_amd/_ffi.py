@@ -113,6 +113,7 @@ EXPORTS = [
     "mrt_abi_version", "mrt_device_count", "mrt_last_error", "mrt_scene_create", "mrt_scene_destroy",
     "mrt_scene_bvh", "mrt_camera_rays", "mrt_trace_rays", "mrt_render_accumulate",
     "mrt_render_accumulate_device", "mrt_to_image", "mrt_scene_set_option",
+    "mrt_bloom_device", "mrt_bloom", "mrt_to_image_device",
 ]
 
 _lib = None
@@ -155,6 +156,12 @@ def load() -> C.CDLL:
     lib.mrt_to_image.argtypes = [vp, u32, u32, u32, vp]
     lib.mrt_scene_set_option.restype = C.c_int
     lib.mrt_scene_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    lib.mrt_bloom_device.restype = C.c_int
+    lib.mrt_bloom_device.argtypes = [C.c_int, vp, u32, u32, u32, vp, vp]
+    lib.mrt_bloom.restype = C.c_int
+    lib.mrt_bloom.argtypes = [C.c_int, vp, u32, u32, u32, vp]
+    lib.mrt_to_image_device.restype = C.c_int
+    lib.mrt_to_image_device.argtypes = [C.c_int, vp, u32, u32, u32, vp, vp]
     if lib.mrt_abi_version() != MRT_ABI_VERSION:
         raise ImportError("libmrt.so ABI version mismatch; rebuild it")
     _lib = lib

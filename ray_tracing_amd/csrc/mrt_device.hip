@@ -1650,6 +1650,9 @@ int set_error(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
 }
+}  // namespace
+void mrt::set_last_error(const std::string& msg) { g_last_error = msg; }
+namespace {
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \

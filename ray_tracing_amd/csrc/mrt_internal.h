@@ -164,6 +164,9 @@ struct FlatScene {
     bool has_medium = false;
 };
 
+// Sets the calling thread's mrt_last_error() message (for the library's other translation units).
+void set_last_error(const std::string& msg);
+
 // Builds FlatScene from the descriptor. Returns an mrt_status; `err` receives a message.
 int flatten_scene(const mrt_scene_desc* desc, FlatScene* out, std::string* err);
 

@@ -175,11 +175,31 @@ class RayTracer:
         self._next_sample += 1
         return st
 
-    def tracing_loop(self, parallel_image: ParallelImage, num_samples: int) -> ParallelImage:
-        """ray_tracer.rs:469-477 without the bloom post-process: returns accumulation / num_samples."""
+    def post_process(self, rgb_img: ParallelImage, num_samples: int = 1) -> ParallelImage:
+        """`RayTracer::post_process` (ray_tracer.rs:465-467): bloom (ray_tracer/bloom.rs:75-94) of
+        rgb_img / num_samples, on the GPU. Images smaller than 128x128 raise (the reference panics)."""
+        out = np.empty_like(rgb_img.buffer)
+        F.check(self._lib.mrt_bloom(self.world.device, rgb_img.buffer.ctypes.data, rgb_img.width, rgb_img.height,
+                                    num_samples, out.ctypes.data))
+        return ParallelImage(out)
+
+    def tracing_loop(self, parallel_image: ParallelImage, num_samples: int, post_process: bool = True) -> ParallelImage:
+        """ray_tracer.rs:469-477: `num_samples` samples per pixel into `parallel_image`, then returns
+        bloom(accumulation / num_samples). post_process=False returns the linear accumulation /
+        num_samples instead (what the parity protocol compares)."""
         self.trace_part(parallel_image.split(1)[0], num_samples)
         self._next_sample += num_samples
+        if post_process:
+            return self.post_process(parallel_image, num_samples)
         return parallel_image / float(num_samples)
+
+    def bloom_device(self, accum_ptr: int, width: int, height: int, num_samples: int, out_ptr: int, stream: int = 0) -> None:
+        """bloom(accum / num_samples) between device-resident f32 buffers."""
+        F.check(self._lib.mrt_bloom_device(self.world.device, accum_ptr, width, height, num_samples, out_ptr, stream))
+
+    def to_image_device(self, rgb_ptr: int, width: int, height: int, num_samples: int, rgb8_ptr: int, stream: int = 0) -> None:
+        """`ParallelImage::to_image` between device-resident buffers (uint8 output, top row first)."""
+        F.check(self._lib.mrt_to_image_device(self.world.device, rgb_ptr, width, height, num_samples, rgb8_ptr, stream))
 
     def render_device(self, accum_ptr: int, width: int, height: int, spp: int, first_sample: int = 0,
                       x0: int = 0, strip_w: Optional[int] = None, stream: int = 0) -> RenderStats:

@@ -35,6 +35,8 @@ def load():
     lib.oracle_rng_u64.restype = u64
     lib.oracle_rng_u64.argtypes = [u64, u64, u64, u32, u32]
     lib.oracle_to_image.argtypes = [vp, u32, u32, u32, vp]
+    lib.oracle_bloom.argtypes = [vp, u32, u32, u32]
+    lib.oracle_bloom.restype = C.c_int
     _lib = lib
     return lib
 
@@ -97,3 +99,19 @@ class OracleWorld:
         assert self.lib.oracle_sample_radiance(self.handle, width, height, px.ctypes.data, len(px), seed,
                                                sample_index, out.ctypes.data) == 0
         return out
+
+
+def oracle_bloom(accum: np.ndarray, num_samples: int):
+    """bloom(accum / num_samples) by the CPU restatement; None where the reference would panic."""
+    img = np.ascontiguousarray(accum, dtype=np.float32).copy()
+    h, w, _ = img.shape
+    rc = load().oracle_bloom(img.ctypes.data, w, h, num_samples)
+    return img if rc == 0 else None
+
+
+def oracle_to_image(rgb: np.ndarray, num_samples: int) -> np.ndarray:
+    img = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w, _ = img.shape
+    out = np.zeros((h, w, 3), dtype=np.uint8)
+    assert load().oracle_to_image(img.ctypes.data, w, h, num_samples, out.ctypes.data) == 0
+    return out
