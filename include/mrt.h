@@ -315,6 +315,19 @@ int mrt_bloom(int device, const float* accum_rgb, uint32_t width, uint32_t heigh
 int mrt_to_image_device(int device, const float* rgb_device, uint32_t width, uint32_t height,
                         uint32_t num_samples, uint8_t* rgb8_out_device, void* stream);
 
+/* `CurrentShader` (ray_tracer.rs:304-309), selected with
+ * mrt_scene_set_option(scene, "shader", MRT_SHADER_*) as RayTracer::set_shader
+ * does (ray_tracer.rs:409-411); the render entry points then evaluate
+ *   RAYTRACING  RayTracingShader::ray_color (ray_tracer.rs:159-303), the default
+ *   DIFFUSE     DiffuseShader::ray_color (ray_tracer.rs:126-157): emitted colour,
+ *               scatter attenuation, black, or the background of the first hit
+ *   LIGHT_MAP   LightMapShader::ray_color (ray_tracer.rs:83-124): for every
+ *               light, a sampled point on it, a second nearest-hit query towards
+ *               it, and the distance from that hit to the sampled point
+ * Random numbers of LIGHT_MAP: segment 0 for the camera ray and the first
+ * query, segment 1 + i for the sample on light i and the query towards it. */
+enum mrt_shader { MRT_SHADER_RAYTRACING = 0, MRT_SHADER_DIFFUSE = 1, MRT_SHADER_LIGHT_MAP = 2 };
+
 /* Tuning knobs (performance only; results change at most in the order of the
  * f32 accumulation adds, except "trace_zero_throughput"):
  *   "pool_slots"             path slots in flight (default 2^21)
@@ -325,6 +338,7 @@ int mrt_to_image_device(int device, const float* rgb_device, uint32_t width, uin
  *   "trace_zero_throughput"  1: keep walking paths whose throughput is exactly
  *                            zero, as the reference does (same image, counters
  *                            match the reference's)
+ * and one that selects what is computed: "shader" (MRT_SHADER_*, see above).
  * Returns MRT_ERR_INVALID_ARGUMENT for unknown names or values out of range. */
 int mrt_scene_set_option(mrt_scene* scene, const char* name, int64_t value);
 

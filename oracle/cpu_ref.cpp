@@ -1137,9 +1137,47 @@ Rgb ray_color(const Ray& ray, const World& world, uint32_t depth) {
     return div_f64(s.attenuation * c, value);
 }
 
+// ---------------------------------------------------------------- DiffuseShader::ray_color (ray_tracer.rs:126-157)
+Rgb diffuse_color(const Ray& ray, const World& world) {
+    g_rng.seg = 0;
+    auto rec = world.nearest_hit(ray, 0.001f, std::numeric_limits<float>::max());
+    if (!rec) return world.background.color(ray);
+    const MaterialEffect& eff = rec->material_effect;
+    switch (eff.kind) {
+        case EffectKind::Emmit: return eff.emitted;
+        case EffectKind::NoEmmit: return BLACK;
+        default: return eff.scatter.attenuation;
+    }
+}
+
+// ---------------------------------------------------------------- LightMapShader::ray_color (ray_tracer.rs:83-124)
+// Random numbers: the camera ray and the first query are segment 0; the sample on light i and the
+// query towards it are segment 1 + i (the reference draws fresh numbers for every light).
+Rgb light_map_color(const Ray& ray, const World& world) {
+    g_rng.seg = 0;
+    auto record = world.nearest_hit(ray, 0.001f, std::numeric_limits<float>::max());
+    if (!record) return BLACK;
+    Rgb acc = BLACK;
+    for (size_t i = 0; i < world.lights.size(); ++i) {
+        g_rng.seg = 1 + (uint32_t)i;
+        RayAreaInfo area;
+        if (!world.lights[i].generate_ray_in_area(record->position, record->t, &area)) std::abort();
+        Rgb x = BLACK;
+        if (auto r = world.nearest_hit(area.to_area, 0.001f, std::numeric_limits<float>::max())) {
+            V3 t = area.end_point - r->position;
+            double m = std::sqrt(dot(t, t));
+            Rgb o = mul_f64(Rgb{1.f, 1.f, 1.f}, m);
+            x = (o.r != o.r || o.g != o.g || o.b != o.b) ? Rgb{1.f, 0.f, 0.f} : o;
+        }
+        acc = acc + x;
+    }
+    return acc;
+}
+
 struct Scene {
     World world;
     uint64_t bvh_seed;
+    int shader = MRT_SHADER_RAYTRACING;  // CurrentShader, ray_tracer.rs:304-309
 };
 
 bool fail(char* err, size_t errlen, const std::string& msg) {
@@ -1364,7 +1402,7 @@ void flatten_bvh(const BvhTreeNode* n, const std::vector<Object>& objs, double t
 }
 
 // RayTracer::trace_part, ray_tracer.rs:435-463, over columns [x_begin, x_end)
-void trace_part(const World& world, float* accum, uint32_t W, uint32_t H, uint32_t x_begin, uint32_t x_end,
+void trace_part(const World& world, int shader, float* accum, uint32_t W, uint32_t H, uint32_t x_begin, uint32_t x_end,
                 uint64_t seed, uint64_t sample_index) {
     for (uint32_t x = x_begin; x < x_end; ++x) {
         for (uint32_t y = 0; y < H; ++y) {
@@ -1373,7 +1411,9 @@ void trace_part(const World& world, float* accum, uint32_t W, uint32_t H, uint32
             double u = ((double)x + rand_scalar(0.0, 1.0, MRT_DIM_JITTER_U)) / ((double)W - 1.0);
             double v = ((double)y + rand_scalar(0.0, 1.0, MRT_DIM_JITTER_V)) / ((double)H - 1.0);
             Ray r = world.camera->get_ray(u, v);
-            Rgb c = ray_color(r, world, 50);
+            Rgb c = shader == MRT_SHADER_DIFFUSE    ? diffuse_color(r, world)      // ray_tracer.rs:448-454
+                    : shader == MRT_SHADER_LIGHT_MAP ? light_map_color(r, world)
+                                                     : ray_color(r, world, 50);
             float* px = accum + ((size_t)x + (size_t)y * W) * 3;  // parallel_image.rs:328-331
             px[0] += c.r;
             px[1] += c.g;
@@ -1397,6 +1437,13 @@ void* oracle_scene_create(const mrt_scene_desc* desc, char* err, size_t errlen) 
     return s.release();
 }
 void oracle_scene_destroy(void* scene) { delete static_cast<Scene*>(scene); }
+
+// RayTracer::set_shader (ray_tracer.rs:409-411): MRT_SHADER_*
+int oracle_set_shader(void* scene, int shader) {
+    if (!scene || shader < MRT_SHADER_RAYTRACING || shader > MRT_SHADER_LIGHT_MAP) return MRT_ERR_INVALID_ARGUMENT;
+    static_cast<Scene*>(scene)->shader = shader;
+    return MRT_OK;
+}
 
 int oracle_scene_bvh(void* scene, mrt_bvh_node* out, size_t capacity, size_t* n_nodes) {
     auto* s = static_cast<Scene*>(scene);
@@ -1479,7 +1526,7 @@ int oracle_render_accumulate(void* scene, float* accum_rgb, uint32_t width, uint
             g_rng.mode = rng_mode;
             g_rng.mt.seed(mix64(seed ^ (0xA5A5A5A5ULL + th)) + first_sample_index);
             for (uint32_t k = 0; k < spp; ++k)
-                trace_part(s->world, accum_rgb, width, height, xb, xe, seed, first_sample_index + k);
+                trace_part(s->world, s->shader, accum_rgb, width, height, xb, xe, seed, first_sample_index + k);
             rays += g_rng.rays;
             lq += g_rng.light_queries;
         });

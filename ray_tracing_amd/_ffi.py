@@ -18,6 +18,7 @@ MRT_ABI_VERSION = 1
 MRT_OK = 0
 MRT_ERR_INVALID_ARGUMENT = -1
 MRT_ERR_UNSUPPORTED = -2
+MRT_SHADER_RAYTRACING, MRT_SHADER_DIFFUSE, MRT_SHADER_LIGHT_MAP = 0, 1, 2
 MRT_ERR_DEVICE = -3
 MRT_ERR_NO_DEVICE = -4
 MRT_ERR_OUT_OF_MEMORY = -5

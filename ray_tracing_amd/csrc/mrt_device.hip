@@ -1565,6 +1565,101 @@ __global__ void __launch_bounds__(BLOCK, seg_waves(WAVE, FEAT)) k_segments(Scene
     }
 }
 
+// ---- the two single-bounce shaders (CurrentShader::Diffuse / LightMap, ray_tracer.rs:304-309)
+// DiffuseShader::ray_color (ray_tracer.rs:126-157): what HitRecord::new (hittable.rs:414-448) decides
+// for the nearest hit -- emitted colour, scatter attenuation, or black -- or the background.
+template <int FEAT>
+__device__ F3 diffuse_stage(const SceneView& sv, const RayD& ray, const HitD& h, bool hit) {
+    if (!hit) return background_color<FEAT>(sv, ray);
+    const DObjRec* ob = sv.objects + h.obj;
+    Surface s;
+    surface_at<FEAT>(ob, ray, h.t, h.sub, h.pos, s);
+    if ((FEAT & FEAT_OCTREE) != 0 && s.voxel >= 0) {  // VoxelMaterial::Lambertian
+        const mrt_voxel& vx = sv.oct_voxels[s.voxel];
+        return {vx.albedo[0], vx.albedo[1], vx.albedo[2]};
+    }
+    const F3 black{0.f, 0.f, 0.f};
+    switch (ob->mat_kind) {
+        case MRT_MAT_DIFFUSE_LIGHT: return s.front_face ? texture_color<FEAT>(sv, ob, s) : black;  // material.rs:236-248
+        case MRT_MAT_METAL: {  // material.rs:105-124: no scatter record when the reflection points inward
+            D3 reflected = reflect(normalize(s.dir_obj), s.n_obj);
+            return dot(reflected, s.n_obj) > 0.0 ? texture_color<FEAT>(sv, ob, s) : black;
+        }
+        case MRT_MAT_DIELECTRIC: return {ob->color[0], ob->color[1], ob->color[2]};  // material.rs:190-195
+        default: return texture_color<FEAT>(sv, ob, s);  // Lambertian, Isotropic
+    }
+}
+
+// One thread per pixel-sample, no path pool: camera ray, nearest hit, and for the light map one
+// sampled point and one more nearest-hit query per light (LightMapShader::ray_color,
+// ray_tracer.rs:83-124; segment 1 + i addresses the random numbers of light i).
+template <bool WAVE, int FEAT, int MODE>
+__global__ void __launch_bounds__(BLOCK) k_single_bounce(SceneView sv, RenderParams rp, unsigned long long w_begin,
+                                                         unsigned long long w_end, Counters* ctr) {
+    const unsigned long long w = w_begin + (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = w < w_end;
+    RayD ray{{0, 0, 0}, {0, 0, 1}, 0};
+    uint32_t pixel = 0;
+    uint64_t key = 0;
+    if (live) {
+        uint32_t sample, pl, y, xs;
+        divmod_u32(w, (uint32_t)rp.npix_strip, rp.inv_npix_strip, sample, pl);
+        divmod_u32(pl, rp.strip_w, rp.inv_strip_w, y, xs);
+        uint32_t x = rp.x0 + xs;
+        pixel = x + y * rp.width;
+        key = path_key(rp.seed, (uint64_t)pixel, rp.first_sample + sample);
+        ray = camera_ray(sv, x, y, rp.width, rp.height, Rng(key, 0));
+    }
+    Stamps st{};
+    uint32_t rays = live ? 1u : 0u;
+    HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
+    Rng g0(key, 0);
+    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g0, live, h, st) : (live && nearest_hit_lane<FEAT>(sv, ray, g0, h));
+    F3 color{0.f, 0.f, 0.f};
+    if constexpr (MODE == MRT_SHADER_DIFFUSE) {
+        if (live) color = diffuse_stage<FEAT>(sv, ray, h, hit);
+    } else {
+        constexpr int LF = FEAT & ~FEAT_OCTREE;
+        hit = hit && live;
+        D3 pos_w{0, 0, 0};
+        if (hit) {
+            const DObjRec* ob = sv.objects + h.obj;
+            Surface s;
+            surface_at<FEAT>(ob, ray, h.t, h.sub, h.pos, s);
+            pos_w = point_to_world(ob, s.pos_obj);
+        }
+        auto lights = as_const(sv.lights);
+        for (int i = 0; i < sv.n_lights; ++i) {
+            Rng gi(key, 1u + (uint32_t)i);
+            AreaInfo ai;
+            ai.to_area = ray;
+            ai.end_point = {0, 0, 0};
+            if (hit) object_generate<LF>(lights + i, pos_w, h.t, gi, ai);
+            HitD h2{0.0, -1, 0, {0.0, 0.0, 0.0}};
+            bool hit2 = WAVE ? nearest_hit_wave<FEAT>(sv, ai.to_area, gi, hit, h2, st)
+                             : (hit && nearest_hit_lane<FEAT>(sv, ai.to_area, gi, h2));
+            if (hit) rays++;
+            if (hit && hit2) {
+                const DObjRec* ob2 = sv.objects + h2.obj;
+                Surface s2;
+                surface_at<FEAT>(ob2, ai.to_area, h2.t, h2.sub, h2.pos, s2);
+                D3 t = ai.end_point - point_to_world(ob2, s2.pos_obj);
+                float o = (float)magnitude(t);  // m * RgbColor::WHITE narrows m to f32 (rgb_color.rs:138-147)
+                if (o != o) color.r += 1.f;     // is_nan -> RgbColor::new(1, 0, 0)
+                else color.r += o, color.g += o, color.b += o;
+            }
+        }
+    }
+    if (live) {
+        float* px = rp.accum + (size_t)pixel * 3;
+        if (color.r != 0.f) atomicAdd(px + 0, color.r);
+        if (color.g != 0.f) atomicAdd(px + 1, color.g);
+        if (color.b != 0.f) atomicAdd(px + 2, color.b);
+    }
+    rays = wave_sum(rays);
+    if (lane_id() == 0 && rays) atomicAdd(&ctr->rays, (unsigned long long)rays);
+}
+
 __global__ void __launch_bounds__(BLOCK) k_init_pool(Pool pool, uint32_t n, unsigned long long* wave_chunks) {
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i < n) pool.seg[i] = -1;
@@ -1705,6 +1800,7 @@ struct mrt_scene {
     int64_t opt_steps = 32;
     int64_t opt_trace_zero = 0;
     int64_t opt_compact = 1;
+    int64_t opt_shader = MRT_SHADER_RAYTRACING;
     int64_t opt_traversal = 0;  // 0 auto, 1 per-lane, 2 wave-synchronous over the tree, 3 over the leaf list
     const DNodeRec* dev_node_recs = nullptr;
     const DNodeRec* dev_leaf_recs = nullptr;
@@ -1718,6 +1814,8 @@ struct FeatList {};
 using KernelFeats = FeatList<0, FEAT_MEDIUM, FEAT_SPHERE | FEAT_MEDIUM, FEAT_SPHERE | FEAT_SPECULAR | FEAT_TEXTURE | FEAT_SKY,
                              FEAT_SPHERE | FEAT_MEDIUM | FEAT_SPECULAR | FEAT_TEXTURE | FEAT_SKY,
                              FEAT_OCTREE | FEAT_SKY, FEAT_ALL>;
+// The single-bounce shaders (debug views) are instantiated for two sets only.
+using SingleBounceFeats = FeatList<FEAT_ALL & ~FEAT_OCTREE, FEAT_ALL>;
 // Calls f(std::integral_constant<int, M>) for the first instantiated set M that covers `need`.
 template <class F, int M0, int... M>
 static void dispatch_feat(int need, FeatList<M0, M...>, F&& f) {
@@ -1864,6 +1962,46 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
 
     HIP_TRY(hipEventRecord(ev_begin, stream));
     HIP_TRY(hipMemsetAsync(sc->counters, 0, sizeof(Counters), stream));
+    if (sc->opt_shader != MRT_SHADER_RAYTRACING) {
+        // single-bounce shaders: one thread per pixel-sample, in launches of at most 2^28 threads
+        const unsigned long long per_launch = 1ull << 28;
+        uint64_t n_launch = 0;
+        HIP_TRY(hipEventRecord(ek0, stream));
+        for (unsigned long long w0 = 0; w0 < rp.n_work; w0 += per_launch, ++n_launch) {
+            const unsigned long long w1 = std::min(rp.n_work, w0 + per_launch);
+            const dim3 grid((unsigned)((w1 - w0 + BLOCK - 1) / BLOCK)), block(BLOCK);
+            const bool light_map = sc->opt_shader == MRT_SHADER_LIGHT_MAP;
+            dispatch_feat(sc->features, SingleBounceFeats{}, [&](auto feat) {
+                constexpr int FT = decltype(feat)::value;
+                if (wave_sync && light_map)
+                    hipLaunchKernelGGL((k_single_bounce<true, FT, MRT_SHADER_LIGHT_MAP>), grid, block, 0, stream, view, rp, w0, w1, sc->counters);
+                else if (wave_sync)
+                    hipLaunchKernelGGL((k_single_bounce<true, FT, MRT_SHADER_DIFFUSE>), grid, block, 0, stream, view, rp, w0, w1, sc->counters);
+                else if (light_map)
+                    hipLaunchKernelGGL((k_single_bounce<false, FT, MRT_SHADER_LIGHT_MAP>), grid, block, 0, stream, view, rp, w0, w1, sc->counters);
+                else
+                    hipLaunchKernelGGL((k_single_bounce<false, FT, MRT_SHADER_DIFFUSE>), grid, block, 0, stream, view, rp, w0, w1, sc->counters);
+            });
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(ek1, stream));
+        Counters done{};
+        HIP_TRY(hipMemcpyAsync(&done, sc->counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipEventRecord(ev_end, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        float ms = 0.f, total = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ek0, ek1));
+        HIP_TRY(hipEventElapsedTime(&total, ev_begin, ev_end));
+        if (stats) {
+            stats->paths = rp.n_work;
+            stats->rays = done.rays;
+            stats->launches = n_launch;
+            stats->kernel_ms = ms;
+            stats->total_ms = total;
+            stats->segment_kernel_avg_ms = n_launch ? ms / (double)n_launch : 0.0;
+        }
+        return MRT_OK;
+    }
     int cur = 0;
     hipLaunchKernelGGL(k_init_pool, dim3(n_slots / BLOCK), dim3(BLOCK), 0, stream, sc->pool[cur], n_slots, sc->wave_chunks);
     HIP_TRY(hipGetLastError());
@@ -2027,6 +2165,10 @@ int mrt_scene_set_option(mrt_scene* scene, const char* name, int64_t value) {
         scene->opt_trace_zero = value ? 1 : 0;
     } else if (n == "compaction") {
         scene->opt_compact = value ? 1 : 0;
+    } else if (n == "shader") {
+        if (value < MRT_SHADER_RAYTRACING || value > MRT_SHADER_LIGHT_MAP)
+            return set_error(MRT_ERR_INVALID_ARGUMENT, "shader must be one of MRT_SHADER_*");
+        scene->opt_shader = value;
     } else if (n == "traversal") {
         if (value < 0 || value > 3) return set_error(MRT_ERR_INVALID_ARGUMENT, "traversal must be 0..3");
         scene->opt_traversal = value;

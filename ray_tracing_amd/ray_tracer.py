@@ -150,6 +150,10 @@ def _stats(s: F.Stats) -> RenderStats:
     return RenderStats(s.paths, s.rays, s.light_queries, s.launches, s.kernel_ms, s.total_ms, s.segment_kernel_avg_ms)
 
 
+# CurrentShader::names() (ray_tracer.rs:310-318), indexed by MRT_SHADER_*
+CURRENT_SHADER_NAMES = ["Ray Tracing", "Diffuse", "LightMap"]
+
+
 class RayTracer:
     """`RayTracer` with `CurrentShader::Raytracing` (ray_tracer.rs:330-336)."""
 
@@ -159,6 +163,15 @@ class RayTracer:
         self._next_sample = 0
         self._lib = F.load()
         self.last_stats: Optional[RenderStats] = None
+
+    def set_shader(self, shader) -> None:
+        """`RayTracer::set_shader` (ray_tracer.rs:409-411). `shader`: a CurrentShader name
+        ("Ray Tracing", "Diffuse", "LightMap"; ray_tracer.rs:310-329) or an MRT_SHADER_* value."""
+        if isinstance(shader, str):
+            if shader not in CURRENT_SHADER_NAMES:
+                raise ValueError(f"invalid name: {shader}")
+            shader = CURRENT_SHADER_NAMES.index(shader)
+        self.world.set_option("shader", int(shader))
 
     def trace_part(self, part: ParallelImagePart, num_samples: int = 1, first_sample: Optional[int] = None) -> RenderStats:
         """`num_samples` x trace_part (ray_tracer.rs:435-463) over the strip, accumulated into part.image."""

@@ -35,6 +35,7 @@ def load():
     lib.oracle_rng_u64.restype = u64
     lib.oracle_rng_u64.argtypes = [u64, u64, u64, u32, u32]
     lib.oracle_to_image.argtypes = [vp, u32, u32, u32, vp]
+    lib.oracle_set_shader.argtypes = [vp, C.c_int]
     lib.oracle_bloom.argtypes = [vp, u32, u32, u32]
     lib.oracle_bloom.restype = C.c_int
     _lib = lib
@@ -54,6 +55,9 @@ class OracleWorld:
         if getattr(self, "handle", None):
             self.lib.oracle_scene_destroy(self.handle)
             self.handle = None
+
+    def set_shader(self, shader: int) -> None:
+        assert self.lib.oracle_set_shader(self.handle, shader) == 0
 
     def bvh(self):
         n = C.c_size_t(0)
