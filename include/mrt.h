@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MRT_ABI_VERSION 1
+#define MRT_ABI_VERSION 2
 
 /* ---------------------------------------------------------------- status */
 typedef enum mrt_status {
@@ -38,13 +38,15 @@ typedef enum mrt_status {
 
 /* --------------------------------------------------------------- textures
  * cpu_rt/src/ray_tracer/texture.rs: SolidColor :33-44, ImageTexture :191-224,
- * MultiplyTexture :12-32, CheckerTexture :46-70, DebugV :225-239. */
+ * MultiplyTexture :12-32, CheckerTexture :46-70, DebugV :225-239,
+ * Perlin :71-190. */
 enum {
     MRT_TEX_SOLID = 0,    /* color                                         */
     MRT_TEX_IMAGE = 1,    /* image = index into mrt_scene_desc.images      */
     MRT_TEX_MULTIPLY = 2, /* a, b = child texture indices (must be < own)  */
     MRT_TEX_CHECKER = 3,  /* a = odd, b = even                             */
-    MRT_TEX_DEBUG_V = 4
+    MRT_TEX_DEBUG_V = 4,
+    MRT_TEX_PERLIN = 5    /* image = index into mrt_scene_desc.perlins     */
 };
 typedef struct mrt_texture {
     int32_t kind;
@@ -63,6 +65,17 @@ typedef struct mrt_image {
     int32_t height;
     const float* rgb;
 } mrt_image;
+
+/* The random tables of one `Perlin` value (texture.rs:72-77, filled by
+ * `Perlin::default()` :162-180 from the global RNG: 256 normalised random
+ * vectors and three permutations of 0..255). The host draws them; they are
+ * scene data. */
+typedef struct mrt_perlin {
+    double ran_float[256][3];
+    uint32_t perm_x[256];
+    uint32_t perm_y[256];
+    uint32_t perm_z[256];
+} mrt_perlin;
 
 /* -------------------------------------------------------------- materials
  * cpu_rt/src/ray_tracer/material.rs: Lambertian :26-78, Metal :80-134,
@@ -213,6 +226,9 @@ typedef struct mrt_scene_desc {
     mrt_background background;
     mrt_sun sun;
     uint64_t bvh_seed;
+    uint32_t n_perlins;
+    uint32_t reserved;
+    const mrt_perlin* perlins;
 } mrt_scene_desc;
 
 /* Flattened BVH node, pre-order, as exported for inspection. */

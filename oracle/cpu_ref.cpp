@@ -274,6 +274,50 @@ struct CheckerTexture : Texture {  // texture.rs:46-70
         return s < 0.0 ? odd->color(u, v, p) : even->color(u, v, p);
     }
 };
+inline int f64_as_i32(double v) {  // Rust `as i32`: toward zero, saturating, NaN -> 0
+    if (v != v) return 0;
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return (-2147483647 - 1);
+    return (int)v;
+}
+struct PerlinTexture : Texture {  // texture.rs:71-190; the random tables are scene data
+    const mrt_perlin* pn;
+    double noise(V3 point) const {  // :124-149 with trilinear_interp :95-122
+        double u = point.x - std::floor(point.x), v = point.y - std::floor(point.y), w = point.z - std::floor(point.z);
+        int i = f64_as_i32(std::floor(point.x)), j = f64_as_i32(std::floor(point.y)), k = f64_as_i32(std::floor(point.z));
+        V3 c[2][2][2];
+        for (int di = 0; di < 2; ++di)
+            for (int dj = 0; dj < 2; ++dj)
+                for (int dk = 0; dk < 2; ++dk) {
+                    uint32_t idx = pn->perm_x[(i + di) & 255] ^ pn->perm_y[(j + dj) & 255] ^ pn->perm_z[(k + dk) & 255];
+                    c[di][dj][dk] = V3{pn->ran_float[idx][0], pn->ran_float[idx][1], pn->ran_float[idx][2]};
+                }
+        double uu = u * u * (3.0 - 2.0 * u), vv = v * v * (3.0 - 2.0 * v), ww = w * w * (3.0 - 2.0 * w);
+        double accum = 0.0;
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 2; ++b)
+                for (int cc = 0; cc < 2; ++cc) {
+                    V3 weight_v{u - (double)a, v - (double)b, w - (double)cc};
+                    accum += ((double)a * uu + (double)(1 - a) * (1.0 - uu)) * ((double)b * vv + (double)(1 - b) * (1.0 - vv)) *
+                             ((double)cc * ww + (double)(1 - cc) * (1.0 - ww)) * dot(c[a][b][cc], weight_v);
+                }
+        return accum;
+    }
+    double turbulence(V3 point, uint32_t depth) const {  // :150-160
+        double acum = 0.0, weight = 1.0;
+        V3 temp_point = point;
+        for (uint32_t n = 0; n < depth; ++n) {
+            acum += weight * noise(temp_point);
+            weight *= 0.5;
+            temp_point = temp_point * 2.0;
+        }
+        return std::fabs(acum);
+    }
+    Rgb color(double, double, V3 pos) const override {  // :185-189
+        double f = turbulence(pos * 2.0, 7);
+        return {(float)f, (float)f, (float)f};
+    }
+};
 struct DebugV : Texture {  // texture.rs:225-239
     Rgb color(double, double v, V3) const override {
         if (!std::isnan(v)) return {(float)v, (float)v, (float)v};
@@ -965,6 +1009,7 @@ struct Background {
 
 // ---------------------------------------------------------------- World (world.rs:79-114)
 struct World {
+    std::vector<mrt_perlin> perlins;
     std::vector<std::unique_ptr<Image>> images;
     std::vector<std::unique_ptr<Texture>> textures;
     std::vector<std::unique_ptr<Material>> materials;
@@ -1197,6 +1242,8 @@ bool build_scene(const mrt_scene_desc* d, Scene* s, char* err, size_t errlen) {
         im->rgb.assign(d->images[i].rgb, d->images[i].rgb + (size_t)im->width * im->height * 3);
         w.images.push_back(std::move(im));
     }
+    if (d->n_perlins && !d->perlins) return fail(err, errlen, "perlins is NULL");
+    w.perlins.assign(d->perlins, d->perlins + d->n_perlins);
     for (uint32_t i = 0; i < d->n_textures; ++i) {
         const mrt_texture& t = d->textures[i];
         auto child = [&](int32_t c) -> const Texture* {
@@ -1231,6 +1278,13 @@ bool build_scene(const mrt_scene_desc* d, Scene* s, char* err, size_t errlen) {
                 break;
             }
             case MRT_TEX_DEBUG_V: w.textures.push_back(std::make_unique<DebugV>()); break;
+            case MRT_TEX_PERLIN: {
+                if (t.image < 0 || (uint32_t)t.image >= d->n_perlins) return fail(err, errlen, "bad perlin index");
+                auto x = std::make_unique<PerlinTexture>();
+                x->pn = &w.perlins[(size_t)t.image];
+                w.textures.push_back(std::move(x));
+                break;
+            }
             default: return fail(err, errlen, "unknown texture kind");
         }
     }

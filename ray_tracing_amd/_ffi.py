@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MRT_LIBRARY selects another build of the same ABI (e.g. the diagnostic libmrt_stamps.so)
 LIB_PATH = os.environ.get("MRT_LIBRARY") or os.path.join(_HERE, "libmrt.so")
 
-MRT_ABI_VERSION = 1
+MRT_ABI_VERSION = 2
 
 # status codes
 MRT_OK = 0
@@ -24,7 +24,7 @@ MRT_ERR_NO_DEVICE = -4
 MRT_ERR_OUT_OF_MEMORY = -5
 
 # enums
-TEX_SOLID, TEX_IMAGE, TEX_MULTIPLY, TEX_CHECKER, TEX_DEBUG_V = range(5)
+TEX_SOLID, TEX_IMAGE, TEX_MULTIPLY, TEX_CHECKER, TEX_DEBUG_V, TEX_PERLIN = range(6)
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = range(5)
 (SHAPE_SPHERE, SHAPE_MOVING_SPHERE, SHAPE_XY_RECT, SHAPE_XZ_RECT, SHAPE_YZ_RECT, SHAPE_RENDER_BOX,
  SHAPE_CONSTANT_MEDIUM, SHAPE_OCTREE) = range(8)
@@ -87,6 +87,11 @@ class Sun(C.Structure):
                 ("radius", C.c_double)]
 
 
+class Perlin(C.Structure):
+    _fields_ = [("ran_float", (C.c_double * 3) * 256), ("perm_x", C.c_uint32 * 256), ("perm_y", C.c_uint32 * 256),
+                ("perm_z", C.c_uint32 * 256)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("n_textures", C.c_uint32), ("n_images", C.c_uint32),
                 ("n_materials", C.c_uint32), ("n_shapes", C.c_uint32), ("n_objects", C.c_uint32),
@@ -96,7 +101,8 @@ class SceneDesc(C.Structure):
                 ("objects", C.POINTER(Object)), ("lights", C.POINTER(Object)),
                 ("octrees", C.POINTER(Octree)),
                 ("camera", CameraInfo), ("background", Background), ("sun", Sun),
-                ("bvh_seed", C.c_uint64)]
+                ("bvh_seed", C.c_uint64), ("n_perlins", C.c_uint32), ("reserved", C.c_uint32),
+                ("perlins", C.POINTER(Perlin))]
 
 
 class BvhNode(C.Structure):

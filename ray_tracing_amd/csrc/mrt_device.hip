@@ -43,6 +43,7 @@ struct SceneView {
     const DTexture* textures;
     const DImage* images;
     const float* image_pool;
+    const mrt_perlin* perlins;
     const DOctree* octrees;
     const DOctNode* oct_nodes;
     const mrt_voxel* oct_voxels;
@@ -132,7 +133,8 @@ enum : int {
     FEAT_SPECULAR = 8,  // Metal / Dielectric materials
     FEAT_TEXTURE = 16,  // textures other than SolidColor
     FEAT_SKY = 32,      // Sky / SunSky background, or a sun in the sky pdf
-    FEAT_ALL = 63
+    FEAT_PERLIN = 64,   // Perlin textures (implies FEAT_TEXTURE)
+    FEAT_ALL = 127
 };
 
 // ============================================================== small vector math
@@ -914,6 +916,36 @@ __device__ __forceinline__ D3 point_to_world(OP ob, D3 p) {
 }
 
 // ============================================================== textures (texture.rs)
+// Perlin::noise / trilinear_interp / turbulence, texture.rs:95-160
+__device__ __noinline__ double perlin_noise(const mrt_perlin& pn, D3 point) {
+    double fx = floor(point.x), fy = floor(point.y), fz = floor(point.z);
+    double u = point.x - fx, v = point.y - fy, w = point.z - fz;
+    int i = f64_as_i32(fx), j = f64_as_i32(fy), k = f64_as_i32(fz);
+    double uu = u * u * (3.0 - 2.0 * u), vv = v * v * (3.0 - 2.0 * v), ww = w * w * (3.0 - 2.0 * w);
+    double accum = 0.0;
+    for (int di = 0; di < 2; ++di)
+        for (int dj = 0; dj < 2; ++dj)
+            for (int dk = 0; dk < 2; ++dk) {
+                uint32_t idx = pn.perm_x[(i + di) & 255] ^ pn.perm_y[(j + dj) & 255] ^ pn.perm_z[(k + dk) & 255];
+                const double* c = pn.ran_float[idx];
+                double d = (c[0] * (u - (double)di) + c[1] * (v - (double)dj)) + c[2] * (w - (double)dk);  // cgmath dot
+                accum += (((double)di * uu + (double)(1 - di) * (1.0 - uu)) * ((double)dj * vv + (double)(1 - dj) * (1.0 - vv))) *
+                         ((double)dk * ww + (double)(1 - dk) * (1.0 - ww)) * d;
+            }
+    return accum;
+}
+__device__ double perlin_turbulence(const mrt_perlin& pn, D3 point, int depth) {
+    double acum = 0.0, weight = 1.0;
+    D3 tp = point;
+#pragma nounroll
+    for (int n = 0; n < depth; ++n) {
+        acum += weight * perlin_noise(pn, tp);
+        weight *= 0.5;
+        tp = tp * 2.0;
+    }
+    return fabs(acum);
+}
+
 __device__ __forceinline__ uint32_t f64_as_index(double v, uint32_t hi) {  // Rust `as usize` then clamp
     if (!(v > 0.0)) return 0;
     if (v >= (double)hi) return hi;
@@ -951,6 +983,13 @@ __device__ F3 texture_color(const SceneView& sv, const DObjRec* sh, const Surfac
                 if (!have_uv) surface_uv<FEAT>(sh, sf, u, v), have_uv = true;
                 c = (v != v) ? F3{0.f, 0.f, 0.f} : F3{(float)v, (float)v, (float)v};
                 break;
+            case MRT_TEX_PERLIN: {  // texture.rs:185-189
+                if constexpr ((FEAT & FEAT_PERLIN) != 0) {
+                    float f = (float)perlin_turbulence(sv.perlins[t.image], 2.0 * pos, 7);
+                    c = {f, f, f};
+                }
+                break;
+            }
             case MRT_TEX_MULTIPLY:  // texture.rs:29-31
                 if (sp < 8) stack[sp++] = t.b;
                 cur = t.a;
@@ -1812,8 +1851,7 @@ struct mrt_scene {
 template <int... M>
 struct FeatList {};
 using KernelFeats = FeatList<0, FEAT_MEDIUM, FEAT_SPHERE | FEAT_MEDIUM, FEAT_SPHERE | FEAT_SPECULAR | FEAT_TEXTURE | FEAT_SKY,
-                             FEAT_SPHERE | FEAT_MEDIUM | FEAT_SPECULAR | FEAT_TEXTURE | FEAT_SKY,
-                             FEAT_OCTREE | FEAT_SKY, FEAT_ALL>;
+                             FEAT_ALL & ~FEAT_OCTREE, FEAT_OCTREE | FEAT_SKY, FEAT_ALL>;
 // The single-bounce shaders (debug views) are instantiated for two sets only.
 using SingleBounceFeats = FeatList<FEAT_ALL & ~FEAT_OCTREE, FEAT_ALL>;
 // Calls f(std::integral_constant<int, M>) for the first instantiated set M that covers `need`.
@@ -1835,7 +1873,7 @@ static int scene_features(const FlatScene& f) {
     for (const DMaterial& m : f.materials)
         if (m.kind == MRT_MAT_METAL || m.kind == MRT_MAT_DIELECTRIC) need |= FEAT_SPECULAR;
     for (const DTexture& t : f.textures)
-        if (t.kind != MRT_TEX_SOLID) need |= FEAT_TEXTURE;
+        if (t.kind != MRT_TEX_SOLID) need |= FEAT_TEXTURE | (t.kind == MRT_TEX_PERLIN ? FEAT_PERLIN : 0);
     if (f.background.kind != MRT_BG_CONSTANT || f.sun.has_sun) need |= FEAT_SKY;
     return need;
 }
@@ -1878,7 +1916,7 @@ int upload_scene(mrt_scene* sc) {
     if ((rc = m.upload(f.node_recs, &sc->dev_node_recs)) != MRT_OK) return rc;
     if ((rc = m.upload(f.leaf_recs, &sc->dev_leaf_recs)) != MRT_OK) return rc;
     UP(f.obj_recs, objects) UP(f.light_recs, lights)
-    UP(f.textures, textures) UP(f.images, images) UP(f.image_pool, image_pool)
+    UP(f.textures, textures) UP(f.images, images) UP(f.image_pool, image_pool) UP(f.perlins, perlins)
     UP(f.octrees, octrees) UP(f.oct_nodes, oct_nodes) UP(f.oct_voxels, oct_voxels)
 #undef UP
     v.n_nodes = (int32_t)f.node_object.size();

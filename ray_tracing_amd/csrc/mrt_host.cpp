@@ -281,7 +281,7 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
     auto need = [&](uint32_t n, const void* p) { return n == 0 || p != nullptr; };
     if (!need(d->n_textures, d->textures) || !need(d->n_images, d->images) || !need(d->n_materials, d->materials) ||
         !need(d->n_shapes, d->shapes) || !need(d->n_objects, d->objects) || !need(d->n_lights, d->lights) ||
-        !need(d->n_octrees, d->octrees))
+        !need(d->n_octrees, d->octrees) || !need(d->n_perlins, d->perlins))
         return fail(err, MRT_ERR_INVALID_ARGUMENT, "array pointer is NULL with a non-zero count");
     FlatScene& s = *out;
     s = FlatScene{};
@@ -292,6 +292,13 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
         DImage di{im.width, im.height, (uint64_t)s.image_pool.size()};
         s.image_pool.insert(s.image_pool.end(), im.rgb, im.rgb + (size_t)im.width * (size_t)im.height * 3);
         s.images.push_back(di);
+    }
+    for (uint32_t i = 0; i < d->n_perlins; ++i) {
+        const mrt_perlin& pn = d->perlins[i];
+        for (int k = 0; k < 256; ++k)
+            if (pn.perm_x[k] > 255 || pn.perm_y[k] > 255 || pn.perm_z[k] > 255)
+                return fail(err, MRT_ERR_INVALID_ARGUMENT, "perlin: permutation entry out of range");
+        s.perlins.push_back(pn);
     }
     for (uint32_t i = 0; i < d->n_textures; ++i) {
         const mrt_texture& t = d->textures[i];
@@ -307,6 +314,10 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
             case MRT_TEX_CHECKER:
                 if (t.a < 0 || (uint32_t)t.a >= i || t.b < 0 || (uint32_t)t.b >= i)
                     return fail(err, MRT_ERR_INVALID_ARGUMENT, "texture: child index must precede the texture");
+                break;
+            case MRT_TEX_PERLIN:
+                if (t.image < 0 || (uint32_t)t.image >= d->n_perlins)
+                    return fail(err, MRT_ERR_INVALID_ARGUMENT, "texture: bad perlin index");
                 break;
             default: return fail(err, MRT_ERR_INVALID_ARGUMENT, "unknown texture kind");
         }

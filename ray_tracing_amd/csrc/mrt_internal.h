@@ -140,6 +140,7 @@ struct FlatScene {
     std::vector<DTexture> textures;
     std::vector<DImage> images;
     std::vector<float> image_pool;
+    std::vector<mrt_perlin> perlins;
     std::vector<DOctree> octrees;
     std::vector<DOctNode> oct_nodes;
     std::vector<mrt_voxel> oct_voxels;

@@ -13,9 +13,9 @@ from typing import Callable, Dict, Optional
 
 import numpy as np
 
-from .scene import (CameraInfo, ConstantColor, ConstantMedium, Dielectric, DiffuseLight, ImageTexture, Isotropic,
-                    Lambertian, Metal, MovingSphere, MultiplyTexture, Object, RenderBox, Sky, SolidColor, Sphere,
-                    SunSky, Transform, WorldInfo, XYRect, XZRect, YZRect)
+from .scene import (CameraInfo, CheckerTexture, ConstantColor, ConstantMedium, DebugV, Dielectric, DiffuseLight,
+                    ImageTexture, Isotropic, Lambertian, Metal, MovingSphere, MultiplyTexture, Object, Perlin, RenderBox,
+                    Sky, SolidColor, Sphere, SunSky, Transform, WorldInfo, XYRect, XZRect, YZRect)
 
 
 def _dist(a, b) -> float:
@@ -133,6 +133,31 @@ def light_demo(earthmap: np.ndarray) -> WorldInfo:
                      CameraInfo(1.0, 20.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
 
 
+def easy_scene(earthmap: np.ndarray, perlin_seed: int = 0) -> WorldInfo:
+    """world/easy_scene.rs:10-186 ("Easy Scene"): Checker(solid, Perlin) ground sphere, earthmap sphere, two
+    Dielectric spheres (one with a negative radius), a DebugV metal sphere, and four lights of four shape
+    kinds (XYRect, YZRect, RenderBox, Sphere) that are also in the object list. `Perlin::default()` draws
+    its tables from the global RNG (texture.rs:162-180); here they come from `perlin_seed`."""
+    look_at, origin = (0.0, 0.0, -1.0), (10.0, 3.0, 2.0)
+    light = Object(XYRect(-0.5, 0.5, -0.5 + 1.0, 0.5 + 1.0, -2.3, DiffuseLight(SolidColor((0.0, 0.0, 0.5))), False))
+    yz_light = Object(YZRect(-0.5, 0.5, -0.5, 0.5, -3.0, DiffuseLight(SolidColor((0.0, 0.5, 0.0))), False))
+    box_light = Object(RenderBox((-0.2, -0.2 - 0.3, -0.2), (0.2, 0.2 - 0.3, 0.2),
+                                 DiffuseLight(SolidColor((40000.0, 0.0, 0.0)))))
+    sphere_light = Object(Sphere(0.5, (0.0, 1.5, -1.0), DiffuseLight(SolidColor((4.0, 4.0, 4.0)))))
+    objects = [
+        Object(Sphere(100.0, (0.0, -100.5, -1.0),
+                      Lambertian(CheckerTexture(odd=Perlin.default(perlin_seed), even=SolidColor((0.5, 1.0, 0.0)))))),
+        Object(Sphere(0.5, (0.0, 0.0, -1.0), Lambertian(ImageTexture(earthmap)))),
+        Object(Sphere(0.5, (-1.0, 0.0, -1.0), Dielectric(1.5, (1.0, 0.8, 0.8)))),
+        Object(Sphere(-0.45, (-1.0, 0.0, 1.0), Dielectric(1.5, (1.0, 1.0, 1.0)))),
+        Object(Sphere(0.5, (1.0, 0.0, -1.0), Metal(DebugV(), 0.0))),
+        light, yz_light, box_light, sphere_light,
+    ]
+    lights = [Object(light.shape), Object(yz_light.shape), Object(box_light.shape), Object(sphere_light.shape)]
+    return WorldInfo(objects, lights, ConstantColor((0.0, 0.0, 0.0)),
+                     CameraInfo(1.0, 20.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
 def synthetic_earthmap(width: int = 256, height: int = 128) -> np.ndarray:
     """A deterministic stand-in for assets/earthmap.jpg with u8/255 texel values."""
     y, x = np.mgrid[0:height, 0:width]
@@ -194,4 +219,6 @@ SCENARIOS: Dict[str, Callable[[], WorldInfo]] = {
 def build(name: str, earthmap: Optional[np.ndarray] = None) -> WorldInfo:
     if name == "Light Demonstration":
         return light_demo(earthmap if earthmap is not None else synthetic_earthmap())
+    if name == "Easy Scene":
+        return easy_scene(earthmap if earthmap is not None else synthetic_earthmap())
     return SCENARIOS[name]()

@@ -53,6 +53,32 @@ class DebugV(Texture):
     pass
 
 
+@dataclass
+class Perlin(Texture):
+    """texture.rs:71-190. The tables are data: `ran_float` (256, 3) unit vectors, `perm_x/y/z` permutations
+    of 0..255. `Perlin.default(seed)` draws them as `Perlin::default()` does (texture.rs:162-180:
+    normalised `rand_vec()`s, Fisher-Yates permutations :89-94) from a seeded generator."""
+    ran_float: np.ndarray
+    perm_x: np.ndarray
+    perm_y: np.ndarray
+    perm_z: np.ndarray
+
+    @staticmethod
+    def default(seed: int = 0) -> "Perlin":
+        rng = np.random.default_rng(seed)
+        v = rng.random((256, 3))
+        v = v / np.sqrt((v * v).sum(axis=1))[:, None]
+
+        def perm():
+            a = np.arange(256)
+            for i in range(255, -1, -1):
+                j = int(rng.integers(0, i + 1))
+                a[i], a[j] = a[j], a[i]
+            return a
+
+        return Perlin(v, perm(), perm(), perm())
+
+
 # ------------------------------------------------------------------ materials (material.rs)
 class Material:
     pass
@@ -269,6 +295,7 @@ class WorldInfo:
         materials: List[F.Material] = []
         shapes: List[F.Shape] = []
         octrees: List[F.Octree] = []
+        perlins: List[F.Perlin] = []
         out = FlatDesc()
         tex_ids, mat_ids, shape_ids = {}, {}, {}
 
@@ -296,6 +323,19 @@ class WorldInfo:
                 rec.a, rec.b = add_texture(t.odd), add_texture(t.even)
             elif isinstance(t, DebugV):
                 rec.kind = F.TEX_DEBUG_V
+            elif isinstance(t, Perlin):
+                pr = F.Perlin()
+                rf = np.asarray(t.ran_float, dtype=np.float64).reshape(256, 3)
+                for i in range(256):
+                    pr.ran_float[i][:] = [float(x) for x in rf[i]]
+                for name in ("perm_x", "perm_y", "perm_z"):
+                    pm = np.asarray(getattr(t, name), dtype=np.int64).reshape(256)
+                    if sorted(pm.tolist()) != list(range(256)):
+                        raise ValueError(f"Perlin.{name} is not a permutation of 0..255")
+                    getattr(pr, name)[:] = [int(x) for x in pm]
+                perlins.append(pr)
+                rec.kind = F.TEX_PERLIN
+                rec.image = len(perlins) - 1
             else:
                 raise TypeError(f"unsupported texture {type(t).__name__}")
             textures.append(rec)
@@ -397,7 +437,9 @@ class WorldInfo:
         d.abi_version = F.MRT_ABI_VERSION
         ta, ia, ma, sa, oa = (arr_of(F.Texture, textures), arr_of(F.Image, images), arr_of(F.Material, materials),
                               arr_of(F.Shape, shapes), arr_of(F.Octree, octrees))
-        out.keep += [ta, ia, ma, sa, oa, objs, lights]
+        pa = arr_of(F.Perlin, perlins)
+        out.keep += [ta, ia, ma, sa, oa, objs, lights, pa]
+        d.n_perlins, d.perlins = len(perlins), pa
         d.n_textures, d.textures = len(textures), ta
         d.n_images, d.images = len(images), ia
         d.n_materials, d.materials = len(materials), ma

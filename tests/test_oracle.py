@@ -141,3 +141,52 @@ def test_independent_rng_mode_is_statistically_consistent():
     b, _ = ow.render(32, 32, 64, seed=1, threads=8, rng_mode=1)
     ma, mb = a.mean(axis=(0, 1)) / 64, b.mean(axis=(0, 1)) / 64
     assert np.abs(ma - mb).max() < 0.05 * ma.max()
+
+
+def test_perlin_texture_against_numpy_restatement():
+    """Perlin::color (texture.rs:95-190) through the diffuse view of a Lambertian(Perlin) wall, against a
+    whole-array numpy restatement evaluated at the checker's own hit positions. Parity unpinned by the
+    reference (no vectors); the two restatements were written separately."""
+    from ray_tracing_amd import _ffi as F
+    from ray_tracing_amd.scene import (CameraInfo, ConstantColor, Lambertian, Object, Perlin, WorldInfo, XYRect)
+    from tests.oracle_ffi import OracleWorld
+    pn = Perlin.default(7)
+    wall = Object(XYRect(-40.0, 40.0, -40.0, 40.0, -3.0, Lambertian(pn), False))
+    cam = CameraInfo(1.0, 60.0, (0.3, 0.2, 5.0), (0.0, 0.0, -3.0), (0.0, 1.0, 0.0), 0.0, 8.0, 0.0, 0.0)
+    info = WorldInfo([wall], [], ConstantColor((0.0, 0.0, 0.0)), cam)
+    ow = OracleWorld(info)
+    W = H = 48
+    ys, xs = np.mgrid[0:H, 0:W]
+    px = np.stack([xs.ravel(), ys.ravel()], 1).astype(np.int32)
+    rays = ow.camera_rays(W, H, px, 5, 0)
+    obj, t, normal, pos, ff = ow.trace_rays(rays, seed=0)
+    assert (obj == 0).all()
+    ow.set_shader(F.MRT_SHADER_DIFFUSE)
+    img, _ = ow.render(W, H, 1, seed=5, threads=1)
+    ow.set_shader(F.MRT_SHADER_RAYTRACING)
+
+    def noise(p):
+        fl = np.floor(p)
+        u, v, w = (p - fl).T
+        i, j, k = fl.astype(np.int64).T
+        uu, vv, ww = u * u * (3 - 2 * u), v * v * (3 - 2 * v), w * w * (3 - 2 * w)
+        acc = np.zeros(len(p))
+        for di in range(2):
+            for dj in range(2):
+                for dk in range(2):
+                    idx = pn.perm_x[(i + di) & 255] ^ pn.perm_y[(j + dj) & 255] ^ pn.perm_z[(k + dk) & 255]
+                    c = pn.ran_float[idx]
+                    d = c[:, 0] * (u - di) + c[:, 1] * (v - dj) + c[:, 2] * (w - dk)
+                    acc += (di * uu + (1 - di) * (1 - uu)) * (dj * vv + (1 - dj) * (1 - vv)) * (dk * ww + (1 - dk) * (1 - ww)) * d
+        return acc
+
+    p = 2.0 * pos
+    acum, weight = np.zeros(len(p)), 1.0
+    for _ in range(7):
+        acum += weight * noise(p)
+        weight *= 0.5
+        p = p * 2.0
+    want = np.abs(acum).astype(np.float32).reshape(H, W)
+    assert want.std() > 0.05                       # it is a pattern, not a constant
+    np.testing.assert_allclose(img[..., 0], want, rtol=1e-5, atol=1e-6)
+    assert (img[..., 0] == img[..., 1]).all() and (img[..., 1] == img[..., 2]).all()
