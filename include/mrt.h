@@ -142,7 +142,11 @@ typedef struct mrt_object {
  * eight node indices in the reference's child order x*4 + y*2 + z
  * (mod.rs `pos_to_index`). */
 enum { MRT_OCT_EMPTY = 0, MRT_OCT_LEAF = 1, MRT_OCT_PARENT = 2 };
-enum { MRT_VOX_LAMBERTIAN = 0, MRT_VOX_REFLECT = 1 };
+/* Voxel (fast_oct_tree/voxel.rs:12-45): Solid(Lambertian | Reflect) or
+ * Volume { density, color, edge_effect }; VolumeEdgeEffect is None or
+ * Solid { hit_probability, solid_material: Lambertian | Reflect }. */
+enum { MRT_VOX_LAMBERTIAN = 0, MRT_VOX_REFLECT = 1, MRT_VOX_VOLUME = 2 };
+enum { MRT_VOX_EDGE_NONE = 0, MRT_VOX_EDGE_LAMBERTIAN = 1, MRT_VOX_EDGE_REFLECT = 2 };
 typedef struct mrt_oct_node {
     int32_t kind;       /* MRT_OCT_*                                         */
     uint32_t size;      /* log2 of the edge length                           */
@@ -150,10 +154,15 @@ typedef struct mrt_oct_node {
     int32_t voxel;      /* index into mrt_octree.voxels for a LEAF           */
 } mrt_oct_node;
 typedef struct mrt_voxel {
-    int32_t kind;   /* MRT_VOX_* (solid voxels; voxel.rs SolidVoxel)         */
-    float albedo[3];
-    float fuzz;
-    int32_t reserved[3];
+    int32_t kind;          /* MRT_VOX_*                                       */
+    float albedo[3];       /* Lambertian / Reflect albedo, Volume colour      */
+    float fuzz;            /* Reflect                                         */
+    int32_t edge_kind;     /* Volume: MRT_VOX_EDGE_*                          */
+    float edge_probability; /* Volume edge: hit_probability                   */
+    float edge_fuzz;       /* Volume edge, Reflect                            */
+    float edge_albedo[3];  /* Volume edge: albedo of the solid material       */
+    int32_t reserved;
+    double density;        /* Volume                                          */
 } mrt_voxel;
 typedef struct mrt_octree {
     uint32_t root;
@@ -397,7 +406,11 @@ enum {
     MRT_DIM_MEDIUM = 0x1000,      /* + ordinal of the ConstantMedium::hit call
                                      within this nearest_hit traversal
                                      (constant_medium.rs:60)                */
-    MRT_DIM_LIGHT_QUERY_MEDIUM = 0x2000 /* same, inside nearest_light_hit   */
+    MRT_DIM_LIGHT_QUERY_MEDIUM = 0x2000, /* same, inside nearest_light_hit  */
+    MRT_DIM_OCT_VOLUME = 0x3000   /* + 2*n + {0 edge effect, 1 free path}: the
+                                     n-th time a ray enters a volume voxel from
+                                     outside any volume, counted over the octree
+                                     walks of one nearest_hit (ray_trace.rs:159,168) */
 };
 
 #ifdef __cplusplus

@@ -175,6 +175,7 @@ struct RngCtx {
     uint64_t key = 0;
     uint32_t seg = 0;
     uint32_t medium_ordinal = 0;
+    uint32_t oct_ordinal = 0;  // volume entries of the octree walks of the current nearest_hit
     bool in_light_query = false;
     int mode = 0;  // 0 counter-based, 1 sequential mt19937_64
     std::mt19937_64 mt;
@@ -442,16 +443,35 @@ struct Isotropic : Material {  // material.rs:251-295
         return s;
     }
 };
-// hittable/fast_oct_tree/voxel.rs:83-117 (solid voxels)
-struct VoxelMaterialLambertian : Material {
-    Rgb albedo;
-    std::optional<ScatterRecord> scatter(const Ray&, const HitRay& rec) const override {
+// VoxelMaterial, hittable/fast_oct_tree/voxel.rs:57-127
+struct VoxelMaterial : Material {
+    enum class Kind { Lambertian, Reflect, Volume } kind = Kind::Lambertian;
+    Rgb color;  // Lambertian color / Reflect albedo / Volume color
+    float fuzz = 0.f;
+    std::optional<ScatterRecord> scatter(const Ray& ray_in, const HitRay& rec) const override {
         ScatterRecord s;
-        s.attenuation = albedo;
-        s.pdf = PdfKind::Lambertian;
-        s.pdf_normal = rec.normal;
-        s.scattering_pdf = SpdfKind::Lambertian;
-        return s;
+        switch (kind) {
+            case Kind::Lambertian:  // :84-89
+                s.attenuation = color;
+                s.pdf = PdfKind::Lambertian;
+                s.pdf_normal = rec.normal;
+                s.scattering_pdf = SpdfKind::Lambertian;
+                return s;
+            case Kind::Volume:  // :90-95
+                s.attenuation = color;
+                s.pdf = PdfKind::Isotropic;
+                s.scattering_pdf = SpdfKind::VoxelVolume;
+                return s;
+            default: {  // Reflect, :96-115
+                V3 reflected = reflect(normalize(ray_in.direction), rec.normal);
+                if (dot(reflected, rec.normal) > 0.0) {
+                    s.specular_ray = Ray{rec.position, reflected + (double)fuzz * rand_unit_vec(MRT_DIM_METAL_FUZZ), ray_in.time};
+                    s.attenuation = color;
+                    return s;
+                }
+                return std::nullopt;
+            }
+        }
     }
 };
 
@@ -751,7 +771,10 @@ struct ConstantMedium : Hittable {
 // ---------------------------------------------------------------- fast_oct_tree/hittable.rs:9-86
 struct OctreeShape : Hittable {
     octref::Tree tree;
-    std::vector<std::unique_ptr<Material>> voxel_materials;  // one per voxel record
+    std::vector<mrt_voxel> voxels;
+    std::vector<VoxelMaterial> voxel_materials;  // the voxel's own material (volume_material() for volumes)
+    std::vector<VoxelMaterial> edge_materials;   // solid_material.to_material() of a volume's edge effect
+    static double rand01(void*, uint32_t index) { return rand_scalar(0.0, 1.0, MRT_DIM_OCT_VOLUME + index); }
     std::optional<HitRecord> hit(const Ray& ray, double t_min, double t_max) const override {
         double ws = (double)tree.world_size();
         Aabb aabb{{0.0, 0.0, 0.0}, {ws, ws, ws}};
@@ -762,12 +785,16 @@ struct OctreeShape : Hittable {
         V3 nd = normalize(ray.direction);
         r.direction[0] = nd.x, r.direction[1] = nd.y, r.direction[2] = nd.z;
         octref::HitInfo info;
-        if (!tree.trace_ray(r, &info)) return std::nullopt;
+        octref::VolumeCtx ctx;
+        ctx.voxels = voxels.data(), ctx.rand01 = &OctreeShape::rand01, ctx.entry = &g_rng.oct_ordinal;
+        if (!tree.trace_ray(r, ctx, &info)) return std::nullopt;
         V3 hp{info.hit_position[0], info.hit_position[1], info.hit_position[2]};
         V3 dp = hp - ray.origin;
         double t = std::sqrt(dot(dp, dp) / dot(ray.direction, ray.direction));
         if (!(t > t_min && t < t_max)) return std::nullopt;
-        const Material* m = voxel_materials[(size_t)info.voxel].get();
+        if (!info.solid)  // volume: normal unit_x, uv origin (hittable.rs:41-60)
+            return make_hit_record(ray, hp, V3{1.0, 0.0, 0.0}, t, 0.0, 0.0, &voxel_materials[(size_t)info.voxel]);
+        const Material* m = info.edge ? &edge_materials[(size_t)info.voxel] : &voxel_materials[(size_t)info.voxel];
         // solid voxels: axis normal, uv (0.5, 0.5)
         V3 n{info.normal[0], info.normal[1], info.normal[2]};
         return make_hit_record(ray, hp, n, t, 0.5, 0.5, m);
@@ -1024,6 +1051,7 @@ struct World {
     std::optional<HitRecord> nearest_hit(const Ray& ray, float t_min, float t_max) const {  // :112-114
         g_rng.rays++;
         g_rng.medium_ordinal = 0;
+        g_rng.oct_ordinal = 0;
         g_rng.in_light_query = false;
         return root->hit(objects, ray, (double)t_min, (double)t_max);
     }
@@ -1387,10 +1415,22 @@ bool build_scene(const mrt_scene_desc* d, Scene* s, char* err, size_t errlen) {
                 std::string e;
                 if (!x->tree.from_linear(o, &e)) return fail(err, errlen, e);
                 for (uint32_t v = 0; v < o.n_voxels; ++v) {
-                    if (o.voxels[v].kind != MRT_VOX_LAMBERTIAN) return fail(err, errlen, "unsupported voxel material");
-                    auto vm = std::make_unique<VoxelMaterialLambertian>();
-                    vm->albedo = {o.voxels[v].albedo[0], o.voxels[v].albedo[1], o.voxels[v].albedo[2]};
-                    x->voxel_materials.push_back(std::move(vm));
+                    const mrt_voxel& vx = o.voxels[v];
+                    VoxelMaterial own, edge;
+                    own.color = {vx.albedo[0], vx.albedo[1], vx.albedo[2]};
+                    own.fuzz = vx.fuzz;
+                    switch (vx.kind) {
+                        case MRT_VOX_LAMBERTIAN: own.kind = VoxelMaterial::Kind::Lambertian; break;
+                        case MRT_VOX_REFLECT: own.kind = VoxelMaterial::Kind::Reflect; break;
+                        case MRT_VOX_VOLUME: own.kind = VoxelMaterial::Kind::Volume; break;
+                        default: return fail(err, errlen, "unknown voxel kind");
+                    }
+                    edge.color = {vx.edge_albedo[0], vx.edge_albedo[1], vx.edge_albedo[2]};
+                    edge.fuzz = vx.edge_fuzz;
+                    edge.kind = vx.edge_kind == MRT_VOX_EDGE_REFLECT ? VoxelMaterial::Kind::Reflect : VoxelMaterial::Kind::Lambertian;
+                    x->voxels.push_back(vx);
+                    x->voxel_materials.push_back(own);
+                    x->edge_materials.push_back(edge);
                 }
                 w.shapes.push_back(std::move(x));
                 break;

@@ -7,7 +7,8 @@
 // get_step_size / in_range (ray_trace.rs:15-83) and trace_ray / ray_iteration for solid voxels
 // (ray_trace.rs:86-698). Leaves carry an integer payload (the reference is generic over the leaf
 // type; its tests use u32 and Voxel leaves); equality of payloads stands for equality of voxels.
-// Volume voxels (handle_volume, ray_trace.rs:118-179) are not restated.
+// Volume voxels (handle_volume / handle_empty, ray_trace.rs:118-199) are walked when a voxel table is
+// given (VolumeCtx); without one every leaf is a solid voxel (the reference's u32 test trees).
 //
 // Pinned by the reference's own unit tests, restated in tests/test_octree.py.
 #ifndef ORACLE_OCTREE_REF_H
@@ -134,11 +135,23 @@ struct Ray {
     double direction[3];
     double time;
 };
+// HitInfo<Voxel> (hit_info.rs): Solid { hit_value, hit_position, normal } or Volume { hit_value,
+// hit_position }. `voxel` indexes the voxel table; `edge` = the hit material is the solid
+// material of that volume voxel's edge effect (ray_trace.rs:155-166), not the voxel's own.
 struct HitInfo {
     double hit_position[3];
     double normal[3];
     int voxel;
     bool solid;
+    bool edge;
+};
+// Voxel table and random source for volume voxels. rand01(user, 2 * n + which): the uniform of the
+// n-th volume entry of this walk; which = 0 edge effect (ray_trace.rs:159), 1 free path (:168).
+struct VolumeCtx {
+    const mrt_voxel* voxels = nullptr;
+    double (*rand01)(void* user, uint32_t index) = nullptr;
+    void* user = nullptr;
+    uint32_t* entry = nullptr;  // running count of volume entries (n above)
 };
 
 struct Tree {
@@ -289,16 +302,85 @@ struct Tree {
         }
     }
 
-    // ray_iteration, ray_trace.rs:86-560, solid voxels only. Returns false for None.
-    bool ray_iteration(P3i block_coordinates, const Ray& ray, HitInfo* out) const {
+    // RayTraceState::volume_distance_left (ray_trace.rs:93-104)
+    struct VolumeState {
+        bool some = false;
+        double distance_left = 0.0, first_density = 0.0;
+        double last_position[3] = {0, 0, 0};
+        int previous = -1;  // previous_volume (index into the voxel table)
+    };
+    enum class Step { Continue, StopVolume, StopSolid };
+    static double dist3(const double* a, const double* b) {  // cgmath distance = (a - b).magnitude()
+        double x = a[0] - b[0], y = a[1] - b[1], z = a[2] - b[2];
+        return std::sqrt(x * x + y * y + z * z);
+    }
+    static void stop_position(const VolumeState& vs, const double* d, double* out) {  // last + left * d.normalize()
+        double inv = 1.0 / std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        for (int a = 0; a < 3; ++a) out[a] = vs.last_position[a] + (d[a] * inv) * vs.distance_left;
+    }
+    // handle_volume, ray_trace.rs:118-179
+    static Step handle_volume(int v, VolumeState& vs, const double* cur, const double* d, const double* normal,
+                              const VolumeCtx& ctx, HitInfo* out) {
+        const mrt_voxel& vm = ctx.voxels[v];
+        if (vs.some) {
+            double previous_density = ctx.voxels[vs.previous].density;
+            double density_ratio = vs.first_density / previous_density;
+            double distance_traveled = dist3(cur, vs.last_position) * density_ratio;
+            if (distance_traveled > vs.distance_left) {
+                stop_position(vs, d, out->hit_position);
+                out->solid = false, out->edge = false, out->voxel = vs.previous;
+                out->normal[0] = 1.0, out->normal[1] = 0.0, out->normal[2] = 0.0;
+                return Step::StopVolume;
+            }
+            vs.distance_left = vs.distance_left - distance_traveled;
+            for (int a = 0; a < 3; ++a) vs.last_position[a] = cur[a];
+            return Step::Continue;
+        }
+        const uint32_t n = (*ctx.entry)++;
+        if (vm.edge_kind != MRT_VOX_EDGE_NONE) {
+            float random_number = (float)ctx.rand01(ctx.user, 2 * n);
+            if (random_number < vm.edge_probability) {
+                out->solid = true, out->edge = true, out->voxel = v;
+                for (int a = 0; a < 3; ++a) out->hit_position[a] = cur[a], out->normal[a] = normal[a];
+                return Step::StopSolid;
+            }
+        }
+        vs.some = true;
+        vs.distance_left = std::log(ctx.rand01(ctx.user, 2 * n + 1)) / (-vm.density);
+        for (int a = 0; a < 3; ++a) vs.last_position[a] = cur[a];
+        vs.first_density = vm.density;
+        vs.previous = v;
+        return Step::Continue;
+    }
+    // handle_empty, ray_trace.rs:180-199
+    static Step handle_empty(VolumeState& vs, const double* cur, const double* d, HitInfo* out) {
+        if (!vs.some) return Step::Continue;
+        double distance_traveled = dist3(cur, vs.last_position);
+        if (distance_traveled > vs.distance_left) {
+            stop_position(vs, d, out->hit_position);
+            out->solid = false, out->edge = false, out->voxel = vs.previous;
+            out->normal[0] = 1.0, out->normal[1] = 0.0, out->normal[2] = 0.0;
+            return Step::StopVolume;
+        }
+        vs.some = false;
+        return Step::Continue;
+    }
+
+    // ray_iteration, ray_trace.rs:86-560. Returns false for None.
+    bool ray_iteration(P3i block_coordinates, const Ray& ray, const double* initial_normal, const VolumeCtx& ctx,
+                       HitInfo* out) const {
         Node chunk;
         if (!get_chunk({(uint32_t)block_coordinates.x, (uint32_t)block_coordinates.y, (uint32_t)block_coordinates.z}, &chunk))
             return false;  // expect("out of range")
         P3i block{floor_size(block_coordinates.x, chunk.size), floor_size(block_coordinates.y, chunk.size),
                   floor_size(block_coordinates.z, chunk.size)};
         double cur[3] = {ray.origin[0], ray.origin[1], ray.origin[2]};
-        // a solid starting cell is ignored (ray_trace.rs:508)
         const double* d = ray.direction;
+        VolumeState vs;
+        // the starting cell: a volume starts the free-path walk, a solid is ignored (ray_trace.rs:476-510)
+        if (chunk.kind == Kind::Leaf && ctx.voxels && ctx.voxels[chunk.leaf].kind == MRT_VOX_VOLUME) {
+            if (handle_volume(chunk.leaf, vs, cur, d, initial_normal, ctx, out) != Step::Continue) return true;
+        }
         double sign_vec[3] = {std::signbit(d[0]) ? 0.0 : 1.0, std::signbit(d[1]) ? 0.0 : 1.0, std::signbit(d[2]) ? 0.0 : 1.0};
         for (int it = 0; it < 3000; ++it) {
             int step_size = get_step_size(block);
@@ -352,25 +434,39 @@ struct Tree {
                 normal[axis] = 1.0;
             }
             block = {bc[0], bc[1], bc[2]};
-            if (node.kind == Kind::Leaf) {  // handle_hit -> StopIterationSolid
-                out->solid = true;
-                out->voxel = node.leaf;
-                for (int a = 0; a < 3; ++a) out->hit_position[a] = cur[a], out->normal[a] = normal[a];
-                return true;
+            // handle_hit, ray_trace.rs:202-221
+            Step s = Step::Continue;
+            if (node.kind == Kind::Leaf) {
+                if (ctx.voxels && ctx.voxels[node.leaf].kind == MRT_VOX_VOLUME) {
+                    s = handle_volume(node.leaf, vs, cur, d, normal, ctx, out);
+                } else {  // StopIterationSolid with the voxel's own material
+                    out->solid = true, out->edge = false;
+                    out->voxel = node.leaf;
+                    for (int a = 0; a < 3; ++a) out->hit_position[a] = cur[a], out->normal[a] = normal[a];
+                    return true;
+                }
+            } else {
+                s = handle_empty(vs, cur, d, out);
             }
-            // Empty: handle_empty with no volume state -> continue
+            if (s != Step::Continue) return true;
         }
         return false;  // "Max number of iterations reached"
     }
+    bool ray_iteration(P3i block_coordinates, const Ray& ray, HitInfo* out) const {
+        static const double unit_x[3] = {1.0, 0.0, 0.0};
+        return ray_iteration(block_coordinates, ray, unit_x, VolumeCtx{}, out);
+    }
 
     // trace_ray, ray_trace.rs:561-683. Returns false for None.
-    bool trace_ray(const Ray& ray, HitInfo* out) const {
+    bool trace_ray(const Ray& ray, HitInfo* out) const { return trace_ray(ray, VolumeCtx{}, out); }
+    bool trace_ray(const Ray& ray, const VolumeCtx& ctx, HitInfo* out) const {
+        static const double unit_x[3] = {1.0, 0.0, 0.0};
         static const int32_t BLOCK_OFFSETS[6][3] = {{0, 0, 0}, {-1, 0, 0}, {0, 0, 0}, {0, -1, 0}, {0, 0, 0}, {0, 0, -1}};
         static const double NORMALS[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
         double ws = (double)world_size();
         const double* o = ray.origin;
         if (o[0] >= 0.0 && o[0] <= ws && o[1] >= 0.0 && o[1] <= ws && o[2] >= 0.0 && o[2] <= ws) {
-            return ray_iteration({f64_as_i32(o[0]), f64_as_i32(o[1]), f64_as_i32(o[2])}, ray, out);
+            return ray_iteration({f64_as_i32(o[0]), f64_as_i32(o[1]), f64_as_i32(o[2])}, ray, unit_x, ctx, out);
         }
         double values[6];
         for (int a = 0; a < 3; ++a) {
@@ -394,8 +490,9 @@ struct Tree {
                f64_as_i32(position[2]) + BLOCK_OFFSETS[min_index][2]};
         int32_t v;
         // `block_coordinate.map(|v| v as u32)`: a negative coordinate wraps to a huge value -> get() = None
-        if (get({(uint32_t)bc.x, (uint32_t)bc.y, (uint32_t)bc.z}, &v)) {
-            out->solid = true;
+        // a solid entry voxel is the hit; a volume or an empty cell starts the walk (ray_trace.rs:651-678)
+        if (get({(uint32_t)bc.x, (uint32_t)bc.y, (uint32_t)bc.z}, &v) && !(ctx.voxels && ctx.voxels[v].kind == MRT_VOX_VOLUME)) {
+            out->solid = true, out->edge = false;
             out->voxel = v;
             for (int a = 0; a < 3; ++a) out->hit_position[a] = position[a], out->normal[a] = NORMALS[min_index][a];
             return true;
@@ -403,7 +500,7 @@ struct Tree {
         Ray r2 = ray;
         for (int a = 0; a < 3; ++a) r2.origin[a] = position[a];
         r2.time = 0.0;
-        return ray_iteration(bc, r2, out);
+        return ray_iteration(bc, r2, NORMALS[min_index], ctx, out);
     }
 
     // Linearised image (one record per reachable node), for handing the tree to the ABI.

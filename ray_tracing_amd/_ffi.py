@@ -29,7 +29,8 @@ MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = ra
 (SHAPE_SPHERE, SHAPE_MOVING_SPHERE, SHAPE_XY_RECT, SHAPE_XZ_RECT, SHAPE_YZ_RECT, SHAPE_RENDER_BOX,
  SHAPE_CONSTANT_MEDIUM, SHAPE_OCTREE) = range(8)
 OCT_EMPTY, OCT_LEAF, OCT_PARENT = range(3)
-VOX_LAMBERTIAN, VOX_REFLECT = range(2)
+VOX_LAMBERTIAN, VOX_REFLECT, VOX_VOLUME = range(3)
+VOX_EDGE_NONE, VOX_EDGE_LAMBERTIAN, VOX_EDGE_REFLECT = range(3)
 BG_SKY, BG_SUN_SKY, BG_CONSTANT = range(3)
 
 
@@ -61,7 +62,9 @@ class OctNode(C.Structure):
 
 
 class Voxel(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("albedo", C.c_float * 3), ("fuzz", C.c_float), ("reserved", C.c_int32 * 3)]
+    _fields_ = [("kind", C.c_int32), ("albedo", C.c_float * 3), ("fuzz", C.c_float), ("edge_kind", C.c_int32),
+                ("edge_probability", C.c_float), ("edge_fuzz", C.c_float), ("edge_albedo", C.c_float * 3),
+                ("reserved", C.c_int32), ("density", C.c_double)]
 
 
 class Octree(C.Structure):

@@ -134,7 +134,8 @@ enum : int {
     FEAT_TEXTURE = 16,  // textures other than SolidColor
     FEAT_SKY = 32,      // Sky / SunSky background, or a sun in the sky pdf
     FEAT_PERLIN = 64,   // Perlin textures (implies FEAT_TEXTURE)
-    FEAT_ALL = 127
+    FEAT_VOLUME = 128,  // volume / reflecting voxels in an octree (implies FEAT_OCTREE)
+    FEAT_ALL = 255
 };
 
 // ============================================================== small vector math
@@ -423,10 +424,78 @@ __device__ __forceinline__ int32_t f64_as_i32(double v) {  // Rust `as i32`: tow
 }
 __device__ __forceinline__ int32_t floor_size(int32_t v, uint32_t s) { return (v >> s) << s; }  // ray_trace.rs:686-688
 
-// ray_iteration (ray_trace.rs:86-560) for solid voxels: walk leaf to leaf until a solid leaf is
-// entered. `cur` starts at the ray origin. Returns false for None. normal_code: 0 -x, 1 +x, 2 -y, 3 +y, 4 -z, 5 +z.
-__device__ bool oct_ray_iteration(const DOctNode* nodes, const DOctree& oc, int32_t bx, int32_t by, int32_t bz, D3 origin,
-                                  D3 d, D3& hit_pos, int& normal_code, int& voxel) {
+// What an octree walk returns, packed into HitD::sub as voxel * OCT_SUB + code:
+//   0..5   solid hit, the voxel's own material, normal code 0 -x, 1 +x, 2 -y, 3 +y, 4 -z, 5 +z
+//   6..11  solid hit by the edge effect of a volume voxel (its solid_material), normal code - 6
+//   12     volume hit: the free path ended inside the volume (material Volume { color }, normal +x)
+constexpr int OCT_SUB = 16;
+constexpr int OCT_EDGE = 6, OCT_VOLUME = 12;
+
+// RayTraceState::volume_distance_left (ray_trace.rs:93-104)
+struct OctVolume {
+    bool some;
+    double distance_left, first_density;
+    D3 last_position;
+    int previous;  // previous_volume: voxel record index
+};
+enum : int { OCT_CONTINUE = 0, OCT_STOP = 1 };
+__device__ __forceinline__ D3 oct_stop_position(const OctVolume& vs, D3 d) {  // last + left * d.normalize()
+    double inv = 1.0 / sqrt(dot(d, d));
+    return vs.last_position + (d * inv) * vs.distance_left;
+}
+// handle_volume, ray_trace.rs:118-179. On OCT_STOP, `code` / `voxel` / `hit_pos` describe the hit.
+__device__ int oct_handle_volume(const mrt_voxel* voxels, int v, OctVolume& vs, D3 cur, D3 d, int normal_code, const Rng& g,
+                                 uint32_t& entry, D3& hit_pos, int& code, int& voxel) {
+    if (vs.some) {
+        double density_ratio = vs.first_density / voxels[vs.previous].density;
+        D3 dl = cur - vs.last_position;
+        double distance_traveled = sqrt(dot(dl, dl)) * density_ratio;
+        if (distance_traveled > vs.distance_left) {
+            hit_pos = oct_stop_position(vs, d);
+            code = OCT_VOLUME, voxel = vs.previous;
+            return OCT_STOP;
+        }
+        vs.distance_left = vs.distance_left - distance_traveled;
+        vs.last_position = cur;
+        return OCT_CONTINUE;
+    }
+    const mrt_voxel& vm = voxels[v];
+    const uint32_t n = entry++;
+    if (vm.edge_kind != MRT_VOX_EDGE_NONE) {
+        float random_number = (float)rand_scalar(g, 0.0, 1.0, MRT_DIM_OCT_VOLUME + 2 * n);
+        if (random_number < vm.edge_probability) {
+            hit_pos = cur;
+            code = OCT_EDGE + normal_code, voxel = v;
+            return OCT_STOP;
+        }
+    }
+    vs.some = true;
+    vs.distance_left = log(rand_scalar(g, 0.0, 1.0, MRT_DIM_OCT_VOLUME + 2 * n + 1)) / (-vm.density);
+    vs.last_position = cur;
+    vs.first_density = vm.density;
+    vs.previous = v;
+    return OCT_CONTINUE;
+}
+// handle_empty, ray_trace.rs:180-199
+__device__ __forceinline__ int oct_handle_empty(OctVolume& vs, D3 cur, D3 d, D3& hit_pos, int& code, int& voxel) {
+    if (!vs.some) return OCT_CONTINUE;
+    D3 dl = cur - vs.last_position;
+    if (sqrt(dot(dl, dl)) > vs.distance_left) {
+        hit_pos = oct_stop_position(vs, d);
+        code = OCT_VOLUME, voxel = vs.previous;
+        return OCT_STOP;
+    }
+    vs.some = false;
+    return OCT_CONTINUE;
+}
+
+// ray_iteration (ray_trace.rs:86-560): walk leaf to leaf until a solid leaf is entered, or (VOL) a
+// volume's edge effect or free path stops the ray. `cur` starts at the ray origin. Returns false
+// for None. `code`: see OCT_SUB.
+template <bool VOL>
+__device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels, const DOctree& oc, int32_t bx, int32_t by,
+                                  int32_t bz, D3 origin, D3 d, int initial_normal, const Rng& g, uint32_t& entry, D3& hit_pos,
+                                  int& code, int& voxel) {
     const int32_t ws = (int32_t)(1u << oc.world_log2);
     auto in_range = [&](int32_t x, int32_t y, int32_t z) {
         return x >= 0 && x < ws && y >= 0 && y < ws && z >= 0 && z < ws;
@@ -436,7 +505,14 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const DOctree& oc, int3
     uint32_t csz = chunk.kind_size >> 8;
     bx = floor_size(bx, csz), by = floor_size(by, csz), bz = floor_size(bz, csz);
     D3 cur = origin;
-    // a solid starting cell is ignored (ray_trace.rs:508)
+    OctVolume vs{false, 0.0, 0.0, {0.0, 0.0, 0.0}, -1};
+    // the starting cell: a volume starts the free-path walk, a solid is ignored (ray_trace.rs:476-510)
+    if constexpr (VOL) {
+        if ((chunk.kind_size & 0xFF) == MRT_OCT_LEAF && voxels[chunk.link].kind == MRT_VOX_VOLUME) {
+            if (oct_handle_volume(voxels, chunk.link, vs, cur, d, initial_normal, g, entry, hit_pos, code, voxel) == OCT_STOP)
+                return true;
+        }
+    }
     const double sx = __builtin_signbit(d.x) ? 0.0 : 1.0, sy = __builtin_signbit(d.y) ? 0.0 : 1.0,
                  sz = __builtin_signbit(d.z) ? 0.0 : 1.0;
     const D3 inv{rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z)};
@@ -448,6 +524,7 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const DOctree& oc, int3
         double tz = ((double)bz + (double)step * sz - cur.z) * inv.z;
         if (tx < 0.0 || ty < 0.0 || tz < 0.0) return false;
         DOctNode node;
+        int normal_code;
         if (tx < ty && tx < tz) {
             cur.y += tx * d.y;
             cur.z += tx * d.z;
@@ -515,10 +592,21 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const DOctree& oc, int3
                 normal_code = 5;
             }
         }
-        if ((node.kind_size & 0xFF) == MRT_OCT_LEAF) {  // handle_hit: StopIterationSolid
-            hit_pos = cur;
-            voxel = node.link;
-            return true;
+        // handle_hit, ray_trace.rs:202-221
+        if ((node.kind_size & 0xFF) == MRT_OCT_LEAF) {
+            bool is_volume = false;
+            if constexpr (VOL) is_volume = voxels[node.link].kind == MRT_VOX_VOLUME;
+            if (!is_volume) {  // StopIterationSolid with the voxel's own material
+                hit_pos = cur;
+                code = normal_code, voxel = node.link;
+                return true;
+            }
+            if constexpr (VOL) {
+                if (oct_handle_volume(voxels, node.link, vs, cur, d, normal_code, g, entry, hit_pos, code, voxel) == OCT_STOP)
+                    return true;
+            }
+        } else if constexpr (VOL) {
+            if (oct_handle_empty(vs, cur, d, hit_pos, code, voxel) == OCT_STOP) return true;
         }
         step = 1 << (node.kind_size >> 8);
     }
@@ -526,12 +614,13 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const DOctree& oc, int3
 }
 
 // FastOctTree::trace_ray (ray_trace.rs:561-683); `d` is the normalised direction.
-__device__ bool oct_trace_ray(const DOctNode* nodes, const DOctree& oc, D3 o, D3 d, D3& hit_pos, int& normal_code,
-                              int& voxel) {
+template <bool VOL>
+__device__ bool oct_trace_ray(const DOctNode* nodes, const mrt_voxel* voxels, const DOctree& oc, D3 o, D3 d, const Rng& g,
+                              uint32_t& entry, D3& hit_pos, int& code, int& voxel) {
     const double ws = (double)(1u << oc.world_log2);
     if (o.x >= 0.0 && o.x <= ws && o.y >= 0.0 && o.y <= ws && o.z >= 0.0 && o.z <= ws) {
-        return oct_ray_iteration(nodes, oc, f64_as_i32(o.x), f64_as_i32(o.y), f64_as_i32(o.z), o, d, hit_pos,
-                                 normal_code, voxel);
+        return oct_ray_iteration<VOL>(nodes, voxels, oc, f64_as_i32(o.x), f64_as_i32(o.y), f64_as_i32(o.z), o, d, 1 /* unit_x */,
+                                      g, entry, hit_pos, code, voxel);
     }
     double v0 = (0.0 - o.x) / d.x, v1 = (ws - o.x) / d.x;
     double v2 = (0.0 - o.y) / d.y, v3 = (ws - o.y) / d.y;
@@ -561,30 +650,35 @@ __device__ bool oct_trace_ray(const DOctNode* nodes, const DOctree& oc, D3 o, D3
     if (bx >= 0 && bx < wsi && by >= 0 && by < wsi && bz >= 0 && bz < wsi) {
         DOctNode n = oct_chunk(nodes, oc.root, bx, by, bz);
         if ((n.kind_size & 0xFF) == MRT_OCT_LEAF) {
-            hit_pos = position;
-            normal_code = min_index;  // NORMALS[min_index]: 0 -x, 1 +x, 2 -y, 3 +y, 4 -z, 5 +z
-            voxel = n.link;
-            return true;
+            bool is_volume = false;
+            if constexpr (VOL) is_volume = voxels[n.link].kind == MRT_VOX_VOLUME;
+            if (!is_volume) {  // a solid entry voxel is the hit (ray_trace.rs:653-657)
+                hit_pos = position;
+                code = min_index;  // NORMALS[min_index]: 0 -x, 1 +x, 2 -y, 3 +y, 4 -z, 5 +z
+                voxel = n.link;
+                return true;
+            }
         }
     }
-    return oct_ray_iteration(nodes, oc, bx, by, bz, position, d, hit_pos, normal_code, voxel);
+    return oct_ray_iteration<VOL>(nodes, voxels, oc, bx, by, bz, position, d, min_index, g, entry, hit_pos, code, voxel);
 }
 
 // Hittable for FastOctTree<Voxel> (fast_oct_tree/hittable.rs:10-68); `sr` is the object-space ray.
-__device__ bool octree_hit(const DOctNode* nodes, const DOctree& oc, const RayD& sr, D3 inv, double t_min, double t_max,
-                           double& t_out, int& sub, D3& pos_out) {
+template <bool VOL>
+__device__ bool octree_hit(const DOctNode* nodes, const mrt_voxel* voxels, const DOctree& oc, const RayD& sr, D3 inv,
+                           double t_min, double t_max, const Rng& g, uint32_t& entry, double& t_out, int& sub, D3& pos_out) {
     if (oc.n_nodes == 0) return false;
     const double ws = (double)(1u << oc.world_log2);
     if (!aabb_hit(D3{0.0, 0.0, 0.0}, D3{ws, ws, ws}, sr, inv, t_min, t_max)) return false;
     D3 nd = normalize(sr.d);
     D3 hp;
-    int ncode, voxel;
-    if (!oct_trace_ray(nodes, oc, sr.o, nd, hp, ncode, voxel)) return false;
+    int code, voxel;
+    if (!oct_trace_ray<VOL>(nodes, voxels, oc, sr.o, nd, g, entry, hp, code, voxel)) return false;
     D3 dp = hp - sr.o;
     double t = sqrt(dot(dp, dp) / dot(sr.d, sr.d));
     if (!(t > t_min && t < t_max)) return false;  // strict, unlike the other shapes
     t_out = t;
-    sub = voxel * 6 + ncode;
+    sub = voxel * OCT_SUB + code;
     pos_out = hp;
     return true;
 }
@@ -600,7 +694,7 @@ template <int FEAT, class PP, class AP>
 __device__ __forceinline__ bool leaf_hit(const SceneView& sv, int kind, int bkind, int octree, PP p,
                                          double neg_inv_density, bool identity, AP to_object, const RayD& ray,
                                          D3 inv_world, double t_min, double t_max, const Rng& g, uint32_t medium_dim,
-                                         double& t, int& sub, D3& pos) {
+                                         uint32_t& oct_entry, double& t, int& sub, D3& pos) {
     RayD sr = ray;
     D3 inv = inv_world;
     if (!identity) {
@@ -608,7 +702,9 @@ __device__ __forceinline__ bool leaf_hit(const SceneView& sv, int kind, int bkin
         inv = {rcp_fast(sr.d.x), rcp_fast(sr.d.y), rcp_fast(sr.d.z)};
     }
     if constexpr ((FEAT & FEAT_OCTREE) != 0) {
-        if (kind == MRT_SHAPE_OCTREE) return octree_hit(sv.oct_nodes, sv.octrees[octree], sr, inv, t_min, t_max, t, sub, pos);
+        if (kind == MRT_SHAPE_OCTREE)
+            return octree_hit<(FEAT & FEAT_VOLUME) != 0>(sv.oct_nodes, sv.oct_voxels, sv.octrees[octree], sr, inv, t_min, t_max, g,
+                                                         oct_entry, t, sub, pos);
     }
     bool medium = false;
     if constexpr ((FEAT & FEAT_MEDIUM) != 0) medium = kind == MRT_SHAPE_CONSTANT_MEDIUM;
@@ -655,16 +751,18 @@ __device__ __forceinline__ bool leaf_hit(const SceneView& sv, int kind, int bkin
 // Leaf test from an object record.
 template <int FEAT, class OP>
 __device__ __forceinline__ bool object_hit(const SceneView& sv, OP ob, const RayD& ray, D3 inv_world, double t_min,
-                                           double t_max, const Rng& g, uint32_t medium_dim, double& t, int& sub, D3& pos) {
+                                           double t_max, const Rng& g, uint32_t medium_dim, uint32_t& oct_entry, double& t,
+                                           int& sub, D3& pos) {
     return leaf_hit<FEAT>(sv, ob->kind, ob->gkind, ob->octree, &ob->p[0], ob->p[9], ob->identity != 0, &ob->to_object, ray,
-                          inv_world, t_min, t_max, g, medium_dim, t, sub, pos);
+                          inv_world, t_min, t_max, g, medium_dim, oct_entry, t, sub, pos);
 }
 // Leaf test of the wave-synchronous walk from a self-contained node record (scalar operands).
 template <int FEAT, class RP>
 __device__ __forceinline__ bool node_hit(const SceneView& sv, RP r, const RayD& ray, D3 inv_world, double t_min,
-                                         double t_max, const Rng& g, uint32_t medium_dim, double& t, int& sub, D3& pos) {
+                                         double t_max, const Rng& g, uint32_t medium_dim, uint32_t& oct_entry, double& t,
+                                         int& sub, D3& pos) {
     return leaf_hit<FEAT>(sv, r->kind, r->kind2, r->octree, &r->p[0], r->p[9], r->identity != 0, &r->to_object, ray,
-                          inv_world, t_min, t_max, g, medium_dim, t, sub, pos);
+                          inv_world, t_min, t_max, g, medium_dim, oct_entry, t, sub, pos);
 }
 
 // Leaf box of a MovingSphere-based object for the time window (t0, t1) the reference passes
@@ -703,7 +801,7 @@ __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng
     double closest = (double)FLT_MAX;
     int best_obj = -1, best_sub = 0;
     D3 best_pos{0.0, 0.0, 0.0};
-    uint32_t medium_ordinal = 0;
+    uint32_t medium_ordinal = 0, oct_entry = 0;
     D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
     int i = 0;
     const int n = sv.n_nodes;
@@ -730,7 +828,7 @@ __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng
                 if (round == 1 && !aabb_hit(mn, mx, ray, inv_d, t_min, closest)) break;
                 double t;
                 int sub;
-                if (object_hit<FEAT>(sv, ob, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
+                if (object_hit<FEAT>(sv, ob, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, oct_entry, t, sub, best_pos)) {
                     closest = t, best_obj = obj, best_sub = sub;
                 }
                 if (is_medium) medium_ordinal++;
@@ -757,7 +855,7 @@ __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng
     double closest = (double)FLT_MAX;
     int best_obj = -1, best_sub = 0;
     D3 best_pos{0.0, 0.0, 0.0};
-    uint32_t medium_ordinal = 0;
+    uint32_t medium_ordinal = 0, oct_entry = 0;
     D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
     const int n = sv.n_wave_nodes;
     auto recs = as_const(sv.node_recs);
@@ -794,7 +892,7 @@ __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng
                 if (pass) {
                     double t;
                     int sub;
-                    if (node_hit<FEAT>(sv, r, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, t, sub, best_pos)) {
+                    if (node_hit<FEAT>(sv, r, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, oct_entry, t, sub, best_pos)) {
                         closest = t, best_obj = obj, best_sub = sub;
                     }
                     if (is_medium) medium_ordinal++;
@@ -820,6 +918,7 @@ struct Surface {
     double t;
     double time;  // object-space ray time (= world ray time)
     int voxel;  // octree hits: index of the voxel record, else -1
+    int voxel_code;  // octree hits: OCT_SUB code (own solid material / edge material / volume)
     int sub;
     bool front_face;  // as the material sees it (object space; `true` for media, constant_medium.rs:66-72)
 };
@@ -871,6 +970,7 @@ __device__ void surface_at(OP ob, const RayD& ray, double t, int sub, D3 oct_pos
     s.t = t;
     s.time = sr.time;
     s.voxel = -1;
+    s.voxel_code = 0;
     s.sub = sub;
     s.n_obj = {1.0, 0.0, 0.0};
     switch (sh->kind) {
@@ -890,11 +990,13 @@ __device__ void surface_at(OP ob, const RayD& ray, double t, int sub, D3 oct_pos
         }
         case MRT_SHAPE_OCTREE: {  // fast_oct_tree/hittable.rs:19-36: position from the walk, axis normal
             if constexpr ((FEAT & FEAT_OCTREE) == 0) break;
-            int code = sub % 6;
+            s.voxel_code = sub % OCT_SUB;
+            int code = s.voxel_code >= OCT_EDGE ? s.voxel_code - OCT_EDGE : s.voxel_code;
             double sg = (code & 1) ? 1.0 : -1.0;
             s.n_obj = {code < 2 ? sg : 0.0, (code == 2 || code == 3) ? sg : 0.0, code >= 4 ? sg : 0.0};
+            if (s.voxel_code == OCT_VOLUME) s.n_obj = {1.0, 0.0, 0.0};  // hittable.rs:49-56
             s.pos_obj = oct_pos;
-            s.voxel = sub / 6;  // VoxelMaterial::Lambertian record
+            s.voxel = sub / OCT_SUB;
             break;
         }
         default: break;  // ConstantMedium: normal (1,0,0), front_face true for the phase function
@@ -1137,7 +1239,7 @@ __device__ void object_generate(OP ob, D3 origin, double time, const Rng& g, Are
 template <int FEAT>
 __device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng& g, uint32_t& light_queries,
                                 double& value) {
-    constexpr int LF = FEAT & ~FEAT_OCTREE;  // an octree is never a light
+    constexpr int LF = FEAT & ~(FEAT_OCTREE | FEAT_VOLUME);  // an octree is never a light
     light_queries++;
     bool any = false;
     double best_t = 0.0;
@@ -1150,7 +1252,8 @@ __device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng&
         double t;
         int sub;
         D3 unused_pos;
-        bool h = object_hit<LF>(sv, lob, ray, inv_d, ray.time, DBL_MAX, g, MRT_DIM_LIGHT_QUERY_MEDIUM + ordinal, t, sub, unused_pos);
+        uint32_t no_octree = 0;
+        bool h = object_hit<LF>(sv, lob, ray, inv_d, ray.time, DBL_MAX, g, MRT_DIM_LIGHT_QUERY_MEDIUM + ordinal, no_octree, t, sub, unused_pos);
         if constexpr ((LF & FEAT_MEDIUM) != 0) {
             if (lob->kind == MRT_SHAPE_CONSTANT_MEDIUM) ordinal++;
         }
@@ -1219,7 +1322,7 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
         // a one-entry list needs no draw (x % 1 == 0; draws are addressed by dimension)
         uint32_t idx = sv.n_lights == 1 ? 0u : rand_u32(g, 0, (uint32_t)sv.n_lights, MRT_DIM_LIGHT_INDEX);
         AreaInfo ai;
-        object_generate<(FEAT & ~FEAT_OCTREE)>(sv.lights + idx, hit_point, incoming_time, g, ai);
+        object_generate<(FEAT & ~(FEAT_OCTREE | FEAT_VOLUME))>(sv.lights + idx, hit_point, incoming_time, g, ai);
         D3 nd = normalize(ai.to_area.d);
         double light_cos = fabs(dot(nd, ai.normal));
         double dist_squared = dot(ai.direction, ai.direction);
@@ -1330,6 +1433,29 @@ __device__ __forceinline__ D3 reflect(D3 v, D3 n) { return v - 2.0 * dot(v, n) *
 // "throughput *= attenuation [/ value]"; the terminal value is emitted light, background or black.
 // Returns true when the path continues with `ray` / `thr` updated; otherwise `radiance` holds the
 // path's contribution (already multiplied by the throughput).
+// Material of a voxel hit (VoxelMaterial, fast_oct_tree/voxel.rs:57-62) in terms of the MRT_MAT_* kinds:
+// Lambertian -> LAMBERTIAN, Reflect -> METAL with the voxel's fuzz, Volume -> MAT_VOXEL_VOLUME.
+constexpr int MAT_VOXEL_VOLUME = 100;
+template <int FEAT>
+__device__ __forceinline__ int voxel_material(const SceneView& sv, const Surface& s, F3& att, double& fuzz) {
+    const mrt_voxel& vx = sv.oct_voxels[s.voxel];
+    att = {vx.albedo[0], vx.albedo[1], vx.albedo[2]};
+    fuzz = 0.0;
+    if constexpr ((FEAT & FEAT_VOLUME) != 0) {
+        if (s.voxel_code == OCT_VOLUME) return MAT_VOXEL_VOLUME;  // VolumeVoxel::volume_material
+        if (s.voxel_code >= OCT_EDGE) {                            // solid_material.to_material() of the edge effect
+            att = {vx.edge_albedo[0], vx.edge_albedo[1], vx.edge_albedo[2]};
+            fuzz = (double)vx.edge_fuzz;
+            return vx.edge_kind == MRT_VOX_EDGE_REFLECT ? (int)MRT_MAT_METAL : (int)MRT_MAT_LAMBERTIAN;
+        }
+        if (vx.kind == MRT_VOX_REFLECT) {
+            fuzz = (double)vx.fuzz;
+            return MRT_MAT_METAL;
+        }
+    }
+    return MRT_MAT_LAMBERTIAN;
+}
+
 // Material response at the nearest hit `h` (or the background when `hit` is false).
 template <int FEAT>
 __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, const HitD& h, bool hit,
@@ -1344,16 +1470,13 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
     const DObjRec* ob = sv.objects + h.obj;
     Surface s;
     surface_at<FEAT>(ob, ray, h.t, h.sub, h.pos, s);
-    // VoxelMaterial::Lambertian (fast_oct_tree/voxel.rs:85-90) behaves as Lambertian with a constant albedo
     const bool voxel_mat = (FEAT & FEAT_OCTREE) != 0 && s.voxel >= 0;
-    const int mkind = voxel_mat ? (int)MRT_MAT_LAMBERTIAN : ob->mat_kind;
+    int mkind = ob->mat_kind;
+    double fuzz = ob->fuzz;
     // Texture value of the material (emitted colour / albedo); evaluated once for every material kind.
     F3 att{ob->color[0], ob->color[1], ob->color[2]};
     if (voxel_mat) {
-        if constexpr ((FEAT & FEAT_OCTREE) != 0) {
-            const mrt_voxel& vx = sv.oct_voxels[s.voxel];
-            att = {vx.albedo[0], vx.albedo[1], vx.albedo[2]};
-        }
+        if constexpr ((FEAT & FEAT_OCTREE) != 0) mkind = voxel_material<FEAT>(sv, s, att, fuzz);
     } else if (mkind != MRT_MAT_DIELECTRIC) {
         att = texture_color<FEAT>(sv, ob, s);
     }
@@ -1364,12 +1487,18 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
             if (s.front_face) radiance = thr * att;
             return false;
         }
+        case MAT_VOXEL_VOLUME:      // voxel.rs:90-95: IsotropicPdf (pdf.rs:63-79) with the Lambertian scattering pdf
         case MRT_MAT_LAMBERTIAN: {  // material.rs:54-64 + ray_tracer.rs:230-268
             D3 pos_w = point_to_world(ob, s.pos_obj);
             D3 n_w = normal_to_world(ob, s.n_obj);
             D3 dir;
             double value;
-            if (!lambertian_generate<FEAT>(sv, s.n_obj, ray.time, pos_w, g, light_queries, dir, value, st)) return false;
+            if ((FEAT & FEAT_VOLUME) != 0 && mkind == MAT_VOXEL_VOLUME) {
+                dir = rand_unit_vec(g, MRT_DIM_ISOTROPIC_PDF);
+                value = 1.0;
+            } else if (!lambertian_generate<FEAT>(sv, s.n_obj, ray.time, pos_w, g, light_queries, dir, value, st)) {
+                return false;
+            }
             double cosine = dot(n_w, normalize(dir));  // Lambertian::scattering_pdf_fn, material.rs:30-41
             if (cosine < 0.0) return false;
             double scattering_pdf = cosine * INV_PI;
@@ -1380,11 +1509,11 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
             break;
         }
         case MRT_MAT_METAL: {  // material.rs:105-124; the specular ray stays in OBJECT space
-            if constexpr ((FEAT & FEAT_SPECULAR) != 0) {
+            if constexpr ((FEAT & (FEAT_SPECULAR | FEAT_VOLUME)) != 0) {  // also VoxelMaterial::Reflect, voxel.rs:96-115
                 D3 reflected = reflect(normalize(s.dir_obj), s.n_obj);
                 if (!(dot(reflected, s.n_obj) > 0.0)) return false;
                 thr = thr * att;
-                ray = {s.pos_obj, reflected + ob->fuzz * rand_unit_vec(g, MRT_DIM_METAL_FUZZ), s.time};
+                ray = {s.pos_obj, reflected + fuzz * rand_unit_vec(g, MRT_DIM_METAL_FUZZ), s.time};
                 break;
             }
             return false;
@@ -1613,11 +1742,19 @@ __device__ F3 diffuse_stage(const SceneView& sv, const RayD& ray, const HitD& h,
     const DObjRec* ob = sv.objects + h.obj;
     Surface s;
     surface_at<FEAT>(ob, ray, h.t, h.sub, h.pos, s);
-    if ((FEAT & FEAT_OCTREE) != 0 && s.voxel >= 0) {  // VoxelMaterial::Lambertian
-        const mrt_voxel& vx = sv.oct_voxels[s.voxel];
-        return {vx.albedo[0], vx.albedo[1], vx.albedo[2]};
-    }
     const F3 black{0.f, 0.f, 0.f};
+    if constexpr ((FEAT & FEAT_OCTREE) != 0) {
+        if (s.voxel >= 0) {  // VoxelMaterial::scatter, voxel.rs:83-117
+            F3 att;
+            double fuzz;
+            int mk = voxel_material<FEAT>(sv, s, att, fuzz);
+            if (mk == MRT_MAT_METAL) {
+                D3 reflected = reflect(normalize(s.dir_obj), s.n_obj);
+                return dot(reflected, s.n_obj) > 0.0 ? att : black;
+            }
+            return att;
+        }
+    }
     switch (ob->mat_kind) {
         case MRT_MAT_DIFFUSE_LIGHT: return s.front_face ? texture_color<FEAT>(sv, ob, s) : black;  // material.rs:236-248
         case MRT_MAT_METAL: {  // material.rs:105-124: no scatter record when the reflection points inward
@@ -1658,7 +1795,7 @@ __global__ void __launch_bounds__(BLOCK) k_single_bounce(SceneView sv, RenderPar
     if constexpr (MODE == MRT_SHADER_DIFFUSE) {
         if (live) color = diffuse_stage<FEAT>(sv, ray, h, hit);
     } else {
-        constexpr int LF = FEAT & ~FEAT_OCTREE;
+        constexpr int LF = FEAT & ~(FEAT_OCTREE | FEAT_VOLUME);
         hit = hit && live;
         D3 pos_w{0, 0, 0};
         if (hit) {
@@ -1850,10 +1987,12 @@ struct mrt_scene {
 // Feature sets the kernels are instantiated for, smallest first; the last one covers everything.
 template <int... M>
 struct FeatList {};
+constexpr int FEAT_NO_OCTREE = FEAT_ALL & ~(FEAT_OCTREE | FEAT_VOLUME);
 using KernelFeats = FeatList<0, FEAT_MEDIUM, FEAT_SPHERE | FEAT_MEDIUM, FEAT_SPHERE | FEAT_SPECULAR | FEAT_TEXTURE | FEAT_SKY,
-                             FEAT_ALL & ~FEAT_OCTREE, FEAT_OCTREE | FEAT_SKY, FEAT_ALL>;
+                             FEAT_NO_OCTREE, FEAT_OCTREE | FEAT_SKY, FEAT_OCTREE | FEAT_SPHERE | FEAT_SKY,
+                             FEAT_OCTREE | FEAT_VOLUME | FEAT_SPHERE | FEAT_SKY, FEAT_ALL>;
 // The single-bounce shaders (debug views) are instantiated for two sets only.
-using SingleBounceFeats = FeatList<FEAT_ALL & ~FEAT_OCTREE, FEAT_ALL>;
+using SingleBounceFeats = FeatList<FEAT_NO_OCTREE, FEAT_ALL>;
 // Calls f(std::integral_constant<int, M>) for the first instantiated set M that covers `need`.
 template <class F, int M0, int... M>
 static void dispatch_feat(int need, FeatList<M0, M...>, F&& f) {
@@ -1875,6 +2014,8 @@ static int scene_features(const FlatScene& f) {
     for (const DTexture& t : f.textures)
         if (t.kind != MRT_TEX_SOLID) need |= FEAT_TEXTURE | (t.kind == MRT_TEX_PERLIN ? FEAT_PERLIN : 0);
     if (f.background.kind != MRT_BG_CONSTANT || f.sun.has_sun) need |= FEAT_SKY;
+    for (const mrt_voxel& v : f.oct_voxels)
+        if (v.kind != MRT_VOX_LAMBERTIAN) need |= FEAT_VOLUME;
     return need;
 }
 

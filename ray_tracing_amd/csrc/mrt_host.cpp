@@ -208,8 +208,12 @@ struct Builder {
     }
 };
 
+// Shapes whose hit() draws random numbers: the two leaves of a span-1 node (bvh.rs:224-232) can then
+// answer differently, so the folded node evaluates them twice.
 bool shape_is_stochastic(const FlatScene& s, int shape) {
-    return s.shapes[(size_t)shape].kind == MRT_SHAPE_CONSTANT_MEDIUM;
+    const DShape& sh = s.shapes[(size_t)shape];
+    if (sh.kind == MRT_SHAPE_OCTREE) return s.octree_has_volume[(size_t)sh.octree] != 0;
+    return sh.kind == MRT_SHAPE_CONSTANT_MEDIUM;
 }
 bool shape_is_dynamic(const FlatScene& s, int shape) {
     const DShape& sh = s.shapes[(size_t)shape];
@@ -369,13 +373,23 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
                 } else if (n.kind == MRT_OCT_LEAF) {
                     if (n.voxel < 0 || (uint32_t)n.voxel >= o.n_voxels)
                         return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: bad voxel index");
-                    if (o.voxels[n.voxel].kind != MRT_VOX_LAMBERTIAN)
-                        return fail(err, MRT_ERR_UNSUPPORTED, "octree: only solid Lambertian voxels are supported");
                     dn.link = (int32_t)(voxel_base + (uint32_t)n.voxel);
                 } else if (n.kind != MRT_OCT_EMPTY) {
                     return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: unknown node kind");
                 }
                 s.oct_nodes.push_back(dn);
+            }
+        }
+        s.octree_has_volume.push_back(0);
+        for (uint32_t v = 0; v < o.n_voxels; ++v) {
+            const mrt_voxel& vx = o.voxels[v];
+            if (vx.kind == MRT_VOX_VOLUME) s.octree_has_volume.back() = 1;
+            if (vx.kind < MRT_VOX_LAMBERTIAN || vx.kind > MRT_VOX_VOLUME)
+                return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: unknown voxel kind");
+            if (vx.kind == MRT_VOX_VOLUME) {
+                if (vx.edge_kind < MRT_VOX_EDGE_NONE || vx.edge_kind > MRT_VOX_EDGE_REFLECT)
+                    return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: unknown volume edge effect");
+                if (!(vx.density > 0.0)) return fail(err, MRT_ERR_INVALID_ARGUMENT, "octree: volume density must be positive");
             }
         }
         s.oct_voxels.insert(s.oct_voxels.end(), o.voxels, o.voxels + o.n_voxels);

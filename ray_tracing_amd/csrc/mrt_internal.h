@@ -142,6 +142,7 @@ struct FlatScene {
     std::vector<float> image_pool;
     std::vector<mrt_perlin> perlins;
     std::vector<DOctree> octrees;
+    std::vector<uint8_t> octree_has_volume;  // per octree: a Volume voxel makes its hit() stochastic
     std::vector<DOctNode> oct_nodes;
     std::vector<mrt_voxel> oct_voxels;
     DCamera camera;

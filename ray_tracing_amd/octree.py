@@ -32,36 +32,82 @@ def from_color_hex(s: str) -> Tuple[float, float, float]:
             float(f(total & 0xFF) / f(255.0)))
 
 
+# Voxel records (fast_oct_tree/voxel.rs:12-45) as rows of VOXEL_ROW float64 values:
+# kind, albedo r g b, fuzz, edge_kind, edge_probability, edge_fuzz, edge albedo r g b, density
+VOXEL_ROW = 12
+
+
+def solid_lambertian(albedo) -> np.ndarray:
+    """Voxel::Solid(SolidVoxel::Lambertian { albedo })"""
+    r = np.zeros(VOXEL_ROW)
+    r[0], r[1:4] = F.VOX_LAMBERTIAN, np.float32(albedo)
+    return r
+
+
+def solid_reflect(albedo, fuzz: float) -> np.ndarray:
+    """Voxel::Solid(SolidVoxel::Reflect { albedo, fuzz })"""
+    r = np.zeros(VOXEL_ROW)
+    r[0], r[1:4], r[4] = F.VOX_REFLECT, np.float32(albedo), np.float32(fuzz)
+    return r
+
+
+def volume(density: float, color, edge_probability: float = 0.0, edge_material: Optional[np.ndarray] = None) -> np.ndarray:
+    """Voxel::Volume(VolumeVoxel { density, color, edge_effect }); edge_material = a solid_lambertian /
+    solid_reflect row for VolumeEdgeEffect::Solid { hit_probability, solid_material }, None for ::None."""
+    r = np.zeros(VOXEL_ROW)
+    r[0], r[1:4], r[11] = F.VOX_VOLUME, np.float32(color), float(density)
+    if edge_material is not None:
+        r[5] = F.VOX_EDGE_REFLECT if edge_material[0] == F.VOX_REFLECT else F.VOX_EDGE_LAMBERTIAN
+        r[6], r[7], r[8:11] = np.float32(edge_probability), edge_material[4], edge_material[1:4]
+    return r
+
+
 class OctTree:
-    """A set of solid Lambertian voxels; later `set` calls overwrite earlier ones."""
+    """A set of voxels; later `set` calls overwrite earlier ones."""
 
     def __init__(self):
         self._coords: List[np.ndarray] = []
-        self._colors: List[np.ndarray] = []
+        self._rows: List[np.ndarray] = []
         self._max = -1
 
-    def set_many(self, coords: np.ndarray, albedo) -> None:
+    def set_rows(self, coords: np.ndarray, rows: np.ndarray) -> None:
+        """FastOctTree::set for every coordinate; `rows`: one voxel record or one per coordinate."""
         coords = np.asarray(coords, dtype=np.int64).reshape(-1, 3)
         if len(coords) == 0:
             return
         if coords.min() < 0:
             raise ValueError("negative voxel coordinate")
+        rows = np.asarray(rows, dtype=np.float64)
+        if rows.ndim == 1:
+            rows = np.broadcast_to(rows, (len(coords), VOXEL_ROW))
+        self._coords.append(coords)
+        self._rows.append(np.ascontiguousarray(rows, dtype=np.float64))
+        self._max = max(self._max, int(coords.max()))
+
+    def set_many(self, coords: np.ndarray, albedo) -> None:
+        """Solid Lambertian voxels with the given albedo (one colour or one per coordinate)."""
+        coords = np.asarray(coords, dtype=np.int64).reshape(-1, 3)
         col = np.asarray(albedo, dtype=np.float32)
         if col.ndim == 1:
             col = np.broadcast_to(col, (len(coords), 3))
-        self._coords.append(coords)
-        self._colors.append(np.ascontiguousarray(col, dtype=np.float32))
-        self._max = max(self._max, int(coords.max()))
+        rows = np.zeros((len(coords), VOXEL_ROW))
+        rows[:, 0], rows[:, 1:4] = F.VOX_LAMBERTIAN, col
+        self.set_rows(coords, rows)
 
     def set(self, albedo, position) -> None:
         self.set_many(np.asarray([position]), albedo)
 
     def voxels(self) -> Tuple[np.ndarray, np.ndarray]:
-        """Final (coords, colours) with overwrites resolved (last set wins)."""
+        """Final (coords, albedo / colour) with overwrites resolved (last set wins)."""
+        c, rows = self.voxel_rows()
+        return c, np.ascontiguousarray(rows[:, 1:4], dtype=np.float32)
+
+    def voxel_rows(self) -> Tuple[np.ndarray, np.ndarray]:
+        """Final (coords, voxel records) with overwrites resolved (last set wins)."""
         if not self._coords:
-            return np.zeros((0, 3), np.int64), np.zeros((0, 3), np.float32)
+            return np.zeros((0, 3), np.int64), np.zeros((0, VOXEL_ROW))
         c = np.concatenate(self._coords)
-        col = np.concatenate(self._colors)
+        col = np.concatenate(self._rows)
         key = (c[:, 0] << 42) | (c[:, 1] << 21) | c[:, 2]
         # keep the LAST occurrence of every key
         order = np.argsort(key[::-1], kind="stable")
@@ -74,10 +120,10 @@ class OctTree:
     def combine(self, other: "OctTree", offset) -> "OctTree":
         """FastOctTree::combine (operations/combine.rs:4-19): other's voxels are set at +offset;
         positions that become negative are dropped."""
-        c, col = other.voxels()
+        c, rows = other.voxel_rows()
         c = c + np.asarray(offset, dtype=np.int64)
         keep = (c >= 0).all(axis=1)
-        self.set_many(c[keep], col[keep])
+        self.set_rows(c[keep], rows[keep])
         return self
 
     def world_log2(self) -> Optional[int]:
@@ -94,12 +140,15 @@ class OctTree:
 
     def linearise(self) -> VoxelGrid:
         """Bottom-up canonical octree -> (nodes, children, voxel table, root)."""
-        coords, colors = self.voxels()
+        coords, rows = self.voxel_rows()
         k = self.world_log2()
         if k is None:
             raise ValueError("empty octree has no bounding box (hittable.rs:69-79 returns None)")
-        table, ids = np.unique(colors.view([("r", "<f4"), ("g", "<f4"), ("b", "<f4")]).reshape(-1), return_inverse=True)
-        voxel_table = np.stack([table["r"], table["g"], table["b"]], axis=1).astype(np.float32)
+        # distinct voxels by exact equality (the reference's VolumeVoxel equality has a 1e-4 margin,
+        # voxel.rs:42-50, which only matters for voxels that differ by less than that)
+        records, ids = np.unique(rows, axis=0, return_inverse=True)
+        ids = np.asarray(ids).reshape(-1)
+        voxel_table = np.ascontiguousarray(records[:, 1:4], dtype=np.float32)
         LEAF, PARENT, EMPTY = F.OCT_LEAF, F.OCT_PARENT, F.OCT_EMPTY
         out_kind: List[np.ndarray] = []
         out_size: List[np.ndarray] = []
@@ -153,7 +202,8 @@ class OctTree:
         nodes["first_child"] = np.concatenate(out_fc)
         nodes["voxel"] = np.concatenate(out_vox)
         children = np.concatenate(children_blocks) if children_blocks else np.zeros(0, np.uint32)
-        return VoxelGrid(nodes=nodes, children=children.astype(np.uint32), voxels=voxel_table, root=n_nodes)
+        return VoxelGrid(nodes=nodes, children=children.astype(np.uint32), voxels=voxel_table, root=n_nodes,
+                         records=records)
 
 
 # ------------------------------------------------------------------ MagicaVoxel .vox (dot_vox 5.1.1 semantics)
@@ -210,9 +260,11 @@ def load_vox(vox: VoxFile) -> OctTree:
 
 def box_points(start, end) -> np.ndarray:
     """IterBox::from_xyz(end).start_xyz(start) (cpu_rt/src/prelude.rs:19-77): x-major, z innermost."""
+    # BoxIter::next (prelude.rs:57-77) stops on x alone; y and z emit their start value even when the
+    # end is not above it (e.g. IterBox::from_xyz(40, 0, 40) is the 40 x 1 x 40 layer y = 0)
     xs = np.arange(start[0], end[0])
-    ys = np.arange(start[1], end[1])
-    zs = np.arange(start[2], end[2])
+    ys = np.arange(start[1], max(end[1], start[1] + 1))
+    zs = np.arange(start[2], max(end[2], start[2] + 1))
     if len(xs) == 0 or len(ys) == 0 or len(zs) == 0:
         return np.zeros((0, 3), np.int64)
     g = np.stack(np.meshgrid(xs, ys, zs, indexing="ij"), axis=-1).reshape(-1, 3)

@@ -182,6 +182,74 @@ def fast_oct_tree_sphere() -> WorldInfo:
                      CameraInfo(1.0, 20.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
 
 
+def _volume_scene(tree, light_origin, light_power: float, background, origin=(-20.0, 5.0, -20.0)) -> WorldInfo:
+    look_at = (5.0, 5.0, 5.0)
+    light = Object(Sphere(1.0, light_origin, DiffuseLight(SolidColor((light_power,) * 3))))
+    return WorldInfo([Object(tree.linearise()), light], [Object(light.shape)], background,
+                     CameraInfo(1.0, 40.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
+def _volume_block(tree, voxel_row) -> None:
+    """The 10 x 8 x 10 block of volume voxels with a solid core that the volume scenarios share
+    (world/fast_oct_tree.rs:346-388)."""
+    from .octree import box_points, solid_lambertian
+    red = solid_lambertian((0.65, 0.05, 0.05))
+    pts = box_points((0, 1, 0), (10, 9, 10))
+    tree.set_rows(pts, voxel_row(pts) if callable(voxel_row) else voxel_row)
+    tree.set_rows(box_points((3, 3, 3), (6, 6, 6)), red)
+    for p in [(0, 0, 0), (0, 1, 0), (5, 5, 5)]:
+        tree.set_rows(np.asarray([p]), red)
+
+
+def volume_two_density() -> WorldInfo:
+    """world/fast_oct_tree.rs:322-407 ("Fast Oct Tree 2 density")."""
+    from .octree import OctTree, volume
+    tree = OctTree()
+
+    def rows(pts):
+        lo, hi = volume(0.3, (0.5, 0.05, 0.5)), volume(0.6, (0.5, 0.05, 0.5))
+        return np.where((pts[:, 1] < 5)[:, None], lo[None, :], hi[None, :])
+
+    _volume_block(tree, rows)
+    return _volume_scene(tree, (50.0, 0.0, 20.0), 500.0, ConstantColor((0.1, 0.1, 0.1)))
+
+
+def volume_lambertian() -> WorldInfo:
+    """world/fast_oct_tree.rs:408-497 ("Fast Oct Tree Volume Lambertian")."""
+    from .octree import OctTree, solid_lambertian, volume
+    tree = OctTree()
+    _volume_block(tree, volume(0.3, (0.5, 0.05, 0.5), 0.6, solid_lambertian((0.5, 0.05, 0.5))))
+    return _volume_scene(tree, (50.0, 0.0, 20.0), 500.0, ConstantColor((0.1, 0.1, 0.1)))
+
+
+def volume_metal() -> WorldInfo:
+    """world/fast_oct_tree.rs:498-594 ("Fast Oct Tree Volume Metal")."""
+    from .octree import OctTree, box_points, solid_lambertian, solid_reflect, volume
+    tree = OctTree()
+    _volume_block(tree, volume(0.3, (0.5, 0.05, 0.5), 0.6, solid_reflect((0.5, 0.05, 0.5), 0.3)))
+    tree.set_rows(box_points((0, 0, 0), (40, 1, 40)), solid_lambertian((0.9, 0.9, 0.9)))
+    return _volume_scene(tree, (0.0, 100.0, 200.0), 1000.0, ConstantColor((0.1, 0.1, 0.1)))
+
+
+def volume_ice() -> WorldInfo:
+    """world/fast_oct_tree.rs:595-690 ("Fast Oct Tree Volume Ice")."""
+    from .octree import OctTree, box_points, from_color_hex, solid_lambertian, solid_reflect, volume
+    ice, snow = from_color_hex("#06068dff"), from_color_hex("#ffffffff")
+    tree = OctTree()
+    pts = box_points((0, 1, 0), (10, 9, 10))
+    snow_row = volume(0.001, snow, 1.0, solid_lambertian(snow))
+    ice_row = volume(0.5, ice, 0.7, solid_reflect(ice, 0.1))
+    tree.set_rows(pts + np.array([10, 0, 10]), np.where((pts[:, 1] >= 8)[:, None], snow_row[None, :], ice_row[None, :]))
+    red = solid_lambertian((0.65, 0.05, 0.05))
+    tree.set_rows(np.asarray([(0, 0, 0)]), red)
+    tree.set_rows(np.asarray([(0, 1, 0)]), red)
+    floor = box_points((0, 0, 0), (40, 0, 40))
+    checker = ((floor[:, 0] + floor[:, 2]) & 1) == 0
+    tree.set_rows(floor, np.where(checker[:, None], solid_lambertian(from_color_hex("#ffffffff"))[None, :],
+                                  solid_lambertian(from_color_hex("#fc0202ff"))[None, :]))
+    return _volume_scene(tree, (0.0, 100.0, 200.0), 500000.0, Sky(0.6), origin=(-20.0, 20.0, -20.0))
+
+
 def load_vox_fixture(path: str):
     """Reads a decoded .vox fixture (tests/golden/*_vox.npz) back into a VoxFile."""
     from .octree import VoxFile
@@ -213,6 +281,10 @@ SCENARIOS: Dict[str, Callable[[], WorldInfo]] = {
     "One Sphere": one_sphere,
     "Two Sphere": two_spheres,
     "Random Scene": random_scene,
+    "Fast Oct Tree 2 density": volume_two_density,
+    "Fast Oct Tree Volume Lambertian": volume_lambertian,
+    "Fast Oct Tree Volume Metal": volume_metal,
+    "Fast Oct Tree Volume Ice": volume_ice,
 }
 
 

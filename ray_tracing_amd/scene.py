@@ -185,8 +185,10 @@ class VoxelGrid(Hittable):
     """Linearised FastOctTree<Voxel>: see ray_tracing_amd.octree.OctTree.linearise()."""
     nodes: np.ndarray      # structured (kind i4, size u4, first_child i4, voxel i4)
     children: np.ndarray   # uint32, 8 per parent
-    voxels: np.ndarray     # float32 (n, 3) Lambertian albedo per distinct voxel
+    voxels: np.ndarray     # float32 (n, 3) albedo / colour per distinct voxel
     root: int
+    records: Optional[np.ndarray] = None  # float64 (n, 12) voxel records (ray_tracing_amd.octree.VOXEL_ROW);
+    #                                       None: every voxel is a solid Lambertian with the colour in `voxels`
 
 
 # ------------------------------------------------------------------ Transform (hittable.rs:64-122)
@@ -395,9 +397,17 @@ class WorldInfo:
             elif isinstance(s, VoxelGrid):
                 nodes = np.ascontiguousarray(s.nodes)
                 children = np.ascontiguousarray(s.children, dtype=np.uint32)
-                vox = np.zeros(len(s.voxels), dtype=np.dtype([("kind", "<i4"), ("albedo", "<f4", 3), ("fuzz", "<f4"),
-                                                              ("reserved", "<i4", 3)]))
+                vox = np.zeros(len(s.voxels), dtype=np.dtype([
+                    ("kind", "<i4"), ("albedo", "<f4", 3), ("fuzz", "<f4"), ("edge_kind", "<i4"),
+                    ("edge_probability", "<f4"), ("edge_fuzz", "<f4"), ("edge_albedo", "<f4", 3), ("reserved", "<i4"),
+                    ("density", "<f8")]))
+                assert vox.dtype.itemsize == C.sizeof(F.Voxel)
                 vox["albedo"] = np.asarray(s.voxels, dtype=np.float32).reshape(-1, 3)
+                if s.records is not None:
+                    rec_ = np.asarray(s.records, dtype=np.float64).reshape(-1, 12)
+                    vox["kind"], vox["albedo"], vox["fuzz"] = rec_[:, 0], rec_[:, 1:4], rec_[:, 4]
+                    vox["edge_kind"], vox["edge_probability"], vox["edge_fuzz"] = rec_[:, 5], rec_[:, 6], rec_[:, 7]
+                    vox["edge_albedo"], vox["density"] = rec_[:, 8:11], rec_[:, 11]
                 out.keep += [nodes, children, vox]
                 o = F.Octree()
                 o.root, o.n_nodes = int(s.root), len(nodes)

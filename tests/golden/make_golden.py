@@ -41,7 +41,8 @@ def main():
 
     # 3. fixed rays -> nearest hit, and small renders, per scene
     for name in ["Cornell Smoke", "Random Scene", "Light Demonstration", "Easy Cornell Box", "Two Sphere",
-                 "Fast Oct Tree Sphere", "Voxel City", "Easy Scene"]:
+                 "Fast Oct Tree Sphere", "Voxel City", "Easy Scene", "Fast Oct Tree 2 density",
+          "Fast Oct Tree Volume Lambertian", "Fast Oct Tree Volume Metal", "Fast Oct Tree Volume Ice"]:
         info = scene_by_name(name)
         ow = oracle_ffi.OracleWorld(info)
         rays = probe_rays(ow, info, n_camera=2048, n_random=2048, seed=5)

@@ -42,7 +42,8 @@ def test_struct_sizes_match_c_layout():
     assert C.sizeof(F.BvhNode) == 56
     assert C.sizeof(F.Stats) == 56
     assert C.sizeof(F.OctNode) == 16
-    assert C.sizeof(F.Voxel) == 32
+    assert C.sizeof(F.Voxel) == 56
+    assert C.sizeof(F.Perlin) == 256 * 3 * 8 + 3 * 256 * 4
 
 
 def _create(info, device=-1):

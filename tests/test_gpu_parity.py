@@ -22,7 +22,8 @@ pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SCENES = ["Cornell Smoke", "Random Scene", "Light Demonstration", "Easy Cornell Box", "Two Sphere",
-          "Fast Oct Tree Sphere", "Voxel City", "Easy Scene"]
+          "Fast Oct Tree Sphere", "Voxel City", "Easy Scene", "Fast Oct Tree 2 density",
+          "Fast Oct Tree Volume Lambertian", "Fast Oct Tree Volume Metal", "Fast Oct Tree Volume Ice"]
 T_RTOL = 1e-5      # north star: within 1e-5 relative hit t and normals
 N_ATOL = 1e-5
 
