@@ -214,6 +214,11 @@ class RayTracer:
         """`ParallelImage::to_image` between device-resident buffers (uint8 output, top row first)."""
         F.check(self._lib.mrt_to_image_device(self.world.device, rgb_ptr, width, height, num_samples, rgb8_ptr, stream))
 
+    def threaded_render(self, image: ParallelImage, samples_per_receive: int = 1) -> "ParallelImageCollector":
+        """`RayTracer::threaded_render` (ray_tracer.rs:479-535): returns the collector that renders
+        progressively into `image`."""
+        return ParallelImageCollector(self, image, samples_per_receive)
+
     def render_device(self, accum_ptr: int, width: int, height: int, spp: int, first_sample: int = 0,
                       x0: int = 0, strip_w: Optional[int] = None, stream: int = 0) -> RenderStats:
         """Accumulates into a device-resident f32 buffer (e.g. a torch tensor's data_ptr())."""
@@ -223,3 +228,47 @@ class RayTracer:
                                                        self.seed, first_sample, stream, C.byref(st)))
         self.last_stats = _stats(st)
         return self.last_stats
+
+
+class ParallelImageCollector:
+    """Progressive rendering with the interface of the reference's `ParallelImageCollector`
+    (cpu_rt/src/parallel_image.rs:395-561) as returned by `RayTracer::threaded_render`
+    (cpu_rt/src/ray_tracer.rs:479-535). The reference keeps eight worker threads that each add one sample
+    per pixel to their strip and send it over a channel; `receive()` joins the newest strips, each
+    divided by the number of samples it holds. Here one GPU renders the whole frame, so `receive()` adds
+    `samples_per_receive` samples per pixel to one accumulation image and returns it divided by the
+    samples taken so far (the same estimator, all strips always in step). `set_shader`, `clear` and
+    `load_scenario` restart the accumulation as the reference's messages do (`part.set_black()`)."""
+
+    def __init__(self, ray_tracer: "RayTracer", image: ParallelImage, samples_per_receive: int = 1):
+        self.ray_tracer = ray_tracer
+        self.image = image
+        self.samples_per_receive = samples_per_receive
+        self.num_samples = 0
+
+    def clear(self) -> None:  # parallel_image.rs:415-417
+        self.image.buffer[...] = 0.0
+        self.num_samples = 0
+
+    def receive(self) -> Optional[ParallelImage]:  # parallel_image.rs:418-438
+        self.ray_tracer.trace_part(self.image.split(1)[0], self.samples_per_receive, first_sample=self.num_samples)
+        self.num_samples += self.samples_per_receive
+        return self.image / float(self.num_samples)
+
+    def set_shader(self, shader) -> None:  # parallel_image.rs:477-487
+        self.ray_tracer.set_shader(shader)
+        self.clear()
+
+    def load_scenario(self, info: WorldInfo) -> None:  # parallel_image.rs:439-462 (the caller builds the WorldInfo)
+        device, seed = self.ray_tracer.world.device, self.ray_tracer.seed
+        self.ray_tracer.world.close()
+        self.ray_tracer.world = World(info, device)
+        self.ray_tracer.seed = seed
+        self.clear()
+
+    def save_image(self, num_samples: int = 1) -> Optional[np.ndarray]:
+        """The 8-bit image `save_file` writes (parallel_image.rs:463-476): the joined image, already a
+        mean, mapped with num_samples = 1."""
+        if self.num_samples == 0:
+            return None
+        return (self.image / float(self.num_samples)).to_image(num_samples)

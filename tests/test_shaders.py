@@ -101,3 +101,28 @@ def test_gpu_shader_option_validation():
         rt.world.set_option("shader", 3)
     with pytest.raises(ValueError):
         rt.set_shader("Bogus")
+
+
+@pytest.mark.gpu
+def test_gpu_collector_progressive_rendering():
+    """ParallelImageCollector::receive semantics: successive calls refine one estimate whose sample set is
+    the union of the calls' sample ranges; set_shader / clear restart it."""
+    info = scenarios.easy_cornell_box()
+    W, H = 64, 48
+    rt = RayTracer(info, device=0, seed=6)
+    col = rt.threaded_render(ParallelImage.new_black(W, H), samples_per_receive=2)
+    first = col.receive().buffer.copy()
+    second = col.receive().buffer.copy()
+    assert col.num_samples == 4
+    once, _ = gpu_render(RayTracer(info, device=0, seed=6), W, H, 4)
+    np.testing.assert_allclose(second, once / np.float32(4.0), rtol=1e-5, atol=1e-6)
+    two, _ = gpu_render(RayTracer(info, device=0, seed=6), W, H, 2)
+    np.testing.assert_allclose(first, two / np.float32(2.0), rtol=1e-5, atol=1e-6)
+    col.set_shader("Diffuse")
+    assert col.num_samples == 0 and col.image.buffer.max() == 0.0
+    d = col.receive().buffer
+    ref = RayTracer(info, device=0, seed=6)
+    ref.set_shader("Diffuse")
+    dd, _ = gpu_render(ref, W, H, 2)
+    np.testing.assert_allclose(d, dd / np.float32(2.0), rtol=1e-5, atol=1e-6)
+    assert col.save_image().shape == (H, W, 3)
