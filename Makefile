@@ -14,13 +14,13 @@ all: lib oracle
 
 lib: $(LIB)
 
-$(LIB): $(CSRC)/mrt_device.hip $(CSRC)/mrt_post.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_internal.h include/mrt.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/mrt_device.hip $(CSRC)/mrt_post.hip $(CSRC)/mrt_host.cpp
+$(LIB): $(CSRC)/mrt_device.hip $(CSRC)/mrt_post.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_octree.cpp $(CSRC)/mrt_internal.h include/mrt.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/mrt_device.hip $(CSRC)/mrt_post.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_octree.cpp
 
 # Diagnostic build: in-kernel cycle stamps per region of the segment kernel (never benchmarked).
 stamps: ray_tracing_amd/libmrt_stamps.so
-ray_tracing_amd/libmrt_stamps.so: $(CSRC)/mrt_device.hip $(CSRC)/mrt_post.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_internal.h include/mrt.h
-	$(HIPCC) $(HIPFLAGS) -DMRT_STAMPS -shared -o $@ $(CSRC)/mrt_device.hip $(CSRC)/mrt_post.hip $(CSRC)/mrt_host.cpp
+ray_tracing_amd/libmrt_stamps.so: $(CSRC)/mrt_device.hip $(CSRC)/mrt_post.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_octree.cpp $(CSRC)/mrt_internal.h include/mrt.h
+	$(HIPCC) $(HIPFLAGS) -DMRT_STAMPS -shared -o $@ $(CSRC)/mrt_device.hip $(CSRC)/mrt_post.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_octree.cpp
 
 oracle: $(ORACLE)
 

@@ -174,6 +174,25 @@ typedef struct mrt_octree {
     const mrt_voxel* voxels;
 } mrt_octree;
 
+/* Host-side construction of an mrt_octree (no GPU involved). The reference
+ * builds FastOctTree<Voxel> with `set` (fast_oct_tree/operations/set.rs:4-36,
+ * mod.rs:43-169: split, recurse, re-collapse equal children), `combine`
+ * (operations/combine.rs:4-19) and `load_vox` (operations/load.rs:74-127);
+ * these entry points produce the same canonical tree from the voxel set.
+ * `xyz` holds n coordinate triples (0 .. 2^21-1); later sets overwrite earlier
+ * ones; `voxels` holds n records, or one when `one_voxel_for_all` is non-zero.
+ * mrt_voxels_linearise fills `out` with pointers owned by the grid, valid until
+ * the grid is changed or destroyed. */
+typedef struct mrt_voxel_grid mrt_voxel_grid;
+mrt_voxel_grid* mrt_voxels_create(void);
+void mrt_voxels_destroy(mrt_voxel_grid* grid);
+int mrt_voxels_set(mrt_voxel_grid* grid, const int32_t* xyz, const mrt_voxel* voxels, size_t n,
+                   int one_voxel_for_all);
+int mrt_voxels_combine(mrt_voxel_grid* dst, const mrt_voxel_grid* src, const int32_t offset[3]);
+int mrt_voxels_load_vox(mrt_voxel_grid* grid, const uint8_t* vox_file_bytes, size_t len);
+size_t mrt_voxels_count(const mrt_voxel_grid* grid);
+int mrt_voxels_linearise(mrt_voxel_grid* grid, mrt_octree* out);
+
 /* ------------------------------------------------------ camera, background
  * camera.rs:14-24 (CameraInfo). Angles in degrees as in the reference. */
 typedef struct mrt_camera_info {

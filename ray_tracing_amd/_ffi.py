@@ -124,6 +124,8 @@ EXPORTS = [
     "mrt_scene_bvh", "mrt_camera_rays", "mrt_trace_rays", "mrt_render_accumulate",
     "mrt_render_accumulate_device", "mrt_to_image", "mrt_scene_set_option",
     "mrt_bloom_device", "mrt_bloom", "mrt_to_image_device",
+    "mrt_voxels_create", "mrt_voxels_destroy", "mrt_voxels_set", "mrt_voxels_combine", "mrt_voxels_load_vox",
+    "mrt_voxels_count", "mrt_voxels_linearise",
 ]
 
 _lib = None
@@ -172,6 +174,19 @@ def load() -> C.CDLL:
     lib.mrt_bloom.argtypes = [C.c_int, vp, u32, u32, u32, vp]
     lib.mrt_to_image_device.restype = C.c_int
     lib.mrt_to_image_device.argtypes = [C.c_int, vp, u32, u32, u32, vp, vp]
+    lib.mrt_voxels_create.restype = vp
+    lib.mrt_voxels_destroy.restype = None
+    lib.mrt_voxels_destroy.argtypes = [vp]
+    lib.mrt_voxels_set.restype = C.c_int
+    lib.mrt_voxels_set.argtypes = [vp, vp, vp, sz, C.c_int]
+    lib.mrt_voxels_combine.restype = C.c_int
+    lib.mrt_voxels_combine.argtypes = [vp, vp, vp]
+    lib.mrt_voxels_load_vox.restype = C.c_int
+    lib.mrt_voxels_load_vox.argtypes = [vp, vp, sz]
+    lib.mrt_voxels_count.restype = sz
+    lib.mrt_voxels_count.argtypes = [vp]
+    lib.mrt_voxels_linearise.restype = C.c_int
+    lib.mrt_voxels_linearise.argtypes = [vp, C.POINTER(Octree)]
     if lib.mrt_abi_version() != MRT_ABI_VERSION:
         raise ImportError("libmrt.so ABI version mismatch; rebuild it")
     _lib = lib

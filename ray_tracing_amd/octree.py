@@ -10,6 +10,7 @@ arrays. Only the query side (`trace_ray`, `ray_iteration`) runs on the GPU.
 """
 from __future__ import annotations
 
+import ctypes as C
 import struct
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -285,3 +286,95 @@ def city_grid(building: OctTree) -> OctTree:
         col = np.where((pts[:, 2] == LINE_POSITION)[:, None], np.float32(line), np.float32(road))
         grid.set_many(pts, col)
     return grid.combine(building, (ROAD_WIDTH, 1, ROAD_WIDTH))
+
+
+# ------------------------------------------------------------------ native builder (C ABI)
+VOXEL_DTYPE = np.dtype([("kind", "<i4"), ("albedo", "<f4", 3), ("fuzz", "<f4"), ("edge_kind", "<i4"),
+                        ("edge_probability", "<f4"), ("edge_fuzz", "<f4"), ("edge_albedo", "<f4", 3), ("reserved", "<i4"),
+                        ("density", "<f8")])
+
+
+def rows_to_voxels(rows: np.ndarray) -> np.ndarray:
+    """VOXEL_ROW rows -> mrt_voxel records."""
+    rows = np.asarray(rows, dtype=np.float64).reshape(-1, VOXEL_ROW)
+    v = np.zeros(len(rows), dtype=VOXEL_DTYPE)
+    v["kind"], v["albedo"], v["fuzz"] = rows[:, 0], rows[:, 1:4], rows[:, 4]
+    v["edge_kind"], v["edge_probability"], v["edge_fuzz"] = rows[:, 5], rows[:, 6], rows[:, 7]
+    v["edge_albedo"], v["density"] = rows[:, 8:11], rows[:, 11]
+    return v
+
+
+class NativeOctTree:
+    """The same interface as OctTree on top of the library's builder (`mrt_voxels_*`, csrc/mrt_octree.cpp):
+    what a compiled host would call. `linearise()` returns a VoxelGrid."""
+
+    def __init__(self):
+        self._lib = F.load()
+        self._h = self._lib.mrt_voxels_create()
+        if not self._h:
+            raise MemoryError("mrt_voxels_create failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.mrt_voxels_destroy(self._h)
+            self._h = None
+
+    def set_rows(self, coords: np.ndarray, rows: np.ndarray) -> None:
+        xyz = np.ascontiguousarray(coords, dtype=np.int32).reshape(-1, 3)
+        rows = np.asarray(rows, dtype=np.float64)
+        one = rows.ndim == 1
+        vox = rows_to_voxels(rows)
+        F.check(self._lib.mrt_voxels_set(self._h, xyz.ctypes.data, vox.ctypes.data, len(xyz), 1 if one else 0))
+
+    def set_many(self, coords: np.ndarray, albedo) -> None:
+        coords = np.asarray(coords).reshape(-1, 3)
+        col = np.asarray(albedo, dtype=np.float32)
+        if col.ndim == 1:
+            self.set_rows(coords, solid_lambertian(col))
+        else:
+            rows = np.zeros((len(coords), VOXEL_ROW))
+            rows[:, 0], rows[:, 1:4] = F.VOX_LAMBERTIAN, col
+            self.set_rows(coords, rows)
+
+    def combine(self, other: "NativeOctTree", offset) -> "NativeOctTree":
+        off = (C.c_int32 * 3)(*[int(v) for v in offset])
+        F.check(self._lib.mrt_voxels_combine(self._h, other._h, off))
+        return self
+
+    def load_vox_bytes(self, data: bytes) -> "NativeOctTree":
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        F.check(self._lib.mrt_voxels_load_vox(self._h, buf, len(data)))
+        return self
+
+    def __len__(self) -> int:
+        return int(self._lib.mrt_voxels_count(self._h))
+
+    def linearise(self) -> VoxelGrid:
+        o = F.Octree()
+        F.check(self._lib.mrt_voxels_linearise(self._h, C.byref(o)))
+        nodes = np.ctypeslib.as_array(C.cast(o.nodes, C.POINTER(C.c_int32)), shape=(o.n_nodes, 4)).copy().view(NODE_DTYPE).reshape(-1)
+        children = (np.ctypeslib.as_array(o.children, shape=(o.n_children,)).copy() if o.n_children
+                    else np.zeros(0, np.uint32))
+        raw = np.ctypeslib.as_array(C.cast(o.voxels, C.POINTER(C.c_uint8)), shape=(o.n_voxels * VOXEL_DTYPE.itemsize,)).copy()
+        vox = raw.view(VOXEL_DTYPE)
+        records = np.zeros((len(vox), VOXEL_ROW))
+        records[:, 0], records[:, 1:4], records[:, 4] = vox["kind"], vox["albedo"], vox["fuzz"]
+        records[:, 5], records[:, 6], records[:, 7] = vox["edge_kind"], vox["edge_probability"], vox["edge_fuzz"]
+        records[:, 8:11], records[:, 11] = vox["edge_albedo"], vox["density"]
+        return VoxelGrid(nodes=nodes, children=children.astype(np.uint32), voxels=np.ascontiguousarray(vox["albedo"]),
+                         root=int(o.root), records=records)
+
+
+def write_vox(models, palette: np.ndarray) -> bytes:
+    """A minimal MagicaVoxel file (MAIN > SIZE/XYZI per model, RGBA) from decoded models; the inverse of
+    parse_vox for what load_vox reads. `models`: arrays (n, 4) of x, y, z, i with i = file index - 1."""
+    def chunk(cid: bytes, body: bytes, kids: bytes = b"") -> bytes:
+        return cid + struct.pack("<ii", len(body), len(kids)) + body + kids
+    kids = b""
+    for m in models:
+        m = np.asarray(m, dtype=np.uint8).reshape(-1, 4).copy()
+        m[:, 3] = m[:, 3] + 1
+        kids += chunk(b"SIZE", struct.pack("<iii", 256, 256, 256))
+        kids += chunk(b"XYZI", struct.pack("<i", len(m)) + m.tobytes())
+    kids += chunk(b"RGBA", np.asarray(palette, dtype=np.uint8).reshape(256, 4).tobytes())
+    return b"VOX " + struct.pack("<i", 150) + chunk(b"MAIN", b"", kids)
