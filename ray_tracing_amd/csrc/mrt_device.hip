@@ -64,7 +64,7 @@ struct Pool {
 // the range when a launch ends is kept per wave ([next, end) pairs) for the next launch.
 constexpr uint32_t WORK_CHUNK = 512;
 
-enum : int { ST_REGEN = 0, ST_TRAVERSE, ST_LEAF, ST_SURFACE, ST_LAMBERT_GEN, ST_LIGHT_VALUE, ST_SHADE, ST_ACCUM, ST_TOTAL, ST_MEDIUM_TAIL, ST_CLAIM, ST_COUNT };
+enum : int { ST_REGEN = 0, ST_TRAVERSE, ST_LEAF, ST_SURFACE, ST_LAMBERT_GEN, ST_LIGHT_VALUE, ST_SHADE, ST_ACCUM, ST_TOTAL, ST_MEDIUM_TAIL, ST_CLAIM, ST_GEN_COS, ST_GEN_LIGHT, ST_GEN_SKY, ST_ISOTROPIC, ST_COUNT };
 struct Counters {
     unsigned long long work_next;
     unsigned long long rays;
@@ -73,6 +73,7 @@ struct Counters {
     unsigned int compacted;
     unsigned long long held;  // work items claimed by waves but not started when the launch ended
     unsigned long long stamps[ST_COUNT];  // diagnostic build only
+    unsigned long long stamp_lanes[ST_COUNT];
 };
 
 // Diagnostic build (-DMRT_STAMPS): wave-level cycle shares of the segment kernel's regions.
@@ -81,6 +82,7 @@ struct Counters {
 #ifdef MRT_STAMPS
 struct Stamps {
     unsigned long long acc[ST_COUNT];
+    unsigned long long lanes[ST_COUNT];  // cycles x active lanes (lane utilisation of the region)
 };
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t;
@@ -92,7 +94,7 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 __device__ __forceinline__ void stamp_add(Stamps& st, int i, unsigned long long t0) {
     unsigned long long d = stamp_now() - t0;
     unsigned long long m = __ballot(1);
-    if ((int)__lane_id() == __ffsll((long long)m) - 1) st.acc[i] += d;
+    if ((int)__lane_id() == __ffsll((long long)m) - 1) st.acc[i] += d, st.lanes[i] += d * (unsigned long long)__popcll(m);
 }
 #define REGION_BEGIN(name) unsigned long long name##_t0 = stamp_now()
 #define REGION_END(st, i, name) stamp_add(st, i, name##_t0)
@@ -1317,6 +1319,7 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
         dir = normalize(x * uvw.u + y * uvw.v + z * uvw.w);
         double c = dot(dir, uvw.w);
         own = c <= 0.0 ? 0.0 : c * INV_PI;
+        REGION_END(st, ST_GEN_COS, gen);
     } else if (r == 1) {  // LightPdf::generate, pdf.rs:104-130
         if (sv.n_lights == 0) return false;
         // a one-entry list needs no draw (x % 1 == 0; draws are addressed by dimension)
@@ -1329,6 +1332,7 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
         if (!(light_cos >= 0.000001)) return false;
         own = dist_squared * rcp_fast(light_cos * ai.area);
         dir = nd;
+        REGION_END(st, ST_GEN_LIGHT, gen);
     } else {  // SkyPdf::generate, pdf.rs:154-193
         bool has_sun = false;
         if constexpr ((FEAT & FEAT_SKY) != 0) has_sun = sv.sun.has_sun != 0;
@@ -1345,6 +1349,7 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
             double area = M_PI * (sv.sun.radius * sv.sun.radius);
             own = area / (4.0 * M_PI);
         }
+        REGION_END(st, ST_GEN_SKY, gen);
     }
     REGION_END(st, ST_LAMBERT_GEN, gen);
     RayD value_ray{hit_point, dir, 0.0};
@@ -1545,8 +1550,10 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
             return false;
         }
         default: {  // MRT_MAT_ISOTROPIC, material.rs:274-285
+            REGION_BEGIN(iso);
             thr = thr * att;
             ray = {s.pos_obj, rand_unit_vec(g, MRT_DIM_ISOTROPIC), s.time};
+            REGION_END(st, ST_ISOTROPIC, iso);
             break;
         }
     }
@@ -1707,7 +1714,7 @@ __global__ void __launch_bounds__(BLOCK, seg_waves(WAVE, FEAT)) k_segments(Scene
     REGION_END(st, ST_TOTAL, total);
 #ifdef MRT_STAMPS
     for (int i = 0; i < ST_COUNT; ++i)
-        if (st.acc[i]) atomicAdd(&ctr->stamps[i], st.acc[i]);
+        if (st.acc[i]) atomicAdd(&ctr->stamps[i], st.acc[i]), atomicAdd(&ctr->stamp_lanes[i], st.lanes[i]);
 #endif
     if (in_range) {
         pool.seg[slot] = seg;
@@ -2234,11 +2241,12 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
 #ifdef MRT_STAMPS
     {
         static const char* names[ST_COUNT] = {"regen", "traverse(all)", "  leaf:solid", "surface+texture", "lambert:generate",
-                                              "lambert:light value", "shade(all)", "accumulate", "total", "  leaf:medium", "  regen:claim"};
-        std::fprintf(stderr, "[stamps] wave-cycles per region (share of total)\n");
+                                              "lambert:light value", "shade(all)", "accumulate", "total", "  leaf:medium", "  regen:claim", "  gen:cosine", "  gen:light", "  gen:sky", "isotropic scatter"};
+        std::fprintf(stderr, "[stamps] wave-cycles per region (share of total, active lanes of 64)\n");
         for (int i = 0; i < ST_COUNT; ++i)
-            std::fprintf(stderr, "[stamps] %-22s %14llu  %5.1f%%\n", names[i], host.stamps[i],
-                         100.0 * (double)host.stamps[i] / (double)std::max(1ull, host.stamps[ST_TOTAL]));
+            std::fprintf(stderr, "[stamps] %-22s %14llu  %5.1f%%  lanes %4.1f\n", names[i], host.stamps[i],
+                         100.0 * (double)host.stamps[i] / (double)std::max(1ull, host.stamps[ST_TOTAL]),
+                         (double)host.stamp_lanes[i] / (double)std::max(1ull, host.stamps[i]));
     }
 #endif
     if (stats) {
