@@ -214,6 +214,12 @@ struct Rng {
 __device__ __forceinline__ uint64_t rng_u64(const Rng& g, uint32_t dim) {
     return mix64(g.base + 0x9E3779B97F4A7C15ULL * (uint64_t)(dim + 1));
 }
+// G * (dim + 1), the per-dimension addend of rng_u64, as a value (lets the caller select between
+// compile-time constants per lane instead of multiplying at run time)
+constexpr uint64_t rng_dim_addend(uint32_t dim) { return 0x9E3779B97F4A7C15ULL * (uint64_t)(dim + 1); }
+__device__ __forceinline__ double rng_f64_addend(const Rng& g, uint64_t addend) {
+    return (double)(mix64(g.base + addend) >> 11) * 0x1.0p-53;
+}
 __device__ __forceinline__ double rng_f64(const Rng& g, uint32_t dim) {
     return (double)(rng_u64(g, dim) >> 11) * 0x1.0p-53;
 }
@@ -226,9 +232,12 @@ __device__ __forceinline__ uint32_t rand_u32(const Rng& g, uint32_t mn, uint32_t
     return ((uint32_t)(rng_u64(g, dim) >> 32) % (mx - mn)) + mn;
 }
 // ray_tracer.rs:48-63: rejection sampling inside the unit ball, not normalised
-__device__ D3 rand_unit_vec(const Rng& g, uint32_t base) {
+// (u0, u1): the first two uniforms of the first candidate when the caller has drawn them already
+// (dimensions base and base + 1), else negative.
+__device__ D3 rand_unit_vec(const Rng& g, uint32_t base, double u0 = -1.0, double u1 = -1.0) {
     for (uint32_t k = 0; k < MRT_MAX_REJECT; ++k) {
-        D3 rv{rng_f64(g, base + 3 * k), rng_f64(g, base + 3 * k + 1), rng_f64(g, base + 3 * k + 2)};
+        const bool pre = k == 0 && u0 >= 0.0;
+        D3 rv{pre ? u0 : rng_f64(g, base + 3 * k), pre ? u1 : rng_f64(g, base + 3 * k + 1), rng_f64(g, base + 3 * k + 2)};
         D3 v = 2.0 * (rv - D3{0.5, 0.5, 0.5});
         if (dot(v, v) < 1.0) return v;
     }
@@ -1163,12 +1172,12 @@ struct AreaInfo {  // hittable.rs:450-456
 };
 template <int AXIS>
 __device__ __forceinline__ void rect_generate(double a0, double a1, double b0, double b1, double k, double flip,
-                                              D3 origin, double time, const Rng& g, AreaInfo& o) {
+                                              D3 origin, double time, double ua, double ub, AreaInfo& o) {
     constexpr int IA = AXIS == 0 ? 1 : 0;
     constexpr int IB = AXIS == 2 ? 1 : 2;
     double c[3];
-    c[IA] = rand_scalar(g, a0, a1, MRT_DIM_LIGHT_A);
-    c[IB] = rand_scalar(g, b0, b1, MRT_DIM_LIGHT_B);
+    c[IA] = ua * (a1 - a0) + a0;  // rand_scalar(a0, a1) on the uniform of MRT_DIM_LIGHT_A
+    c[IB] = ub * (b1 - b0) + b0;  // rand_scalar(b0, b1) on the uniform of MRT_DIM_LIGHT_B
     c[AXIS] = k;
     D3 end_point{c[0], c[1], c[2]};
     o.to_area = {origin, normalize(end_point - origin), time};
@@ -1178,7 +1187,7 @@ __device__ __forceinline__ void rect_generate(double a0, double a1, double b0, d
     o.end_point = end_point;
 }
 template <int FEAT, class OP>
-__device__ void shape_generate(OP sh, D3 origin, double time, const Rng& g, AreaInfo& o) {
+__device__ void shape_generate(OP sh, D3 origin, double time, const Rng& g, double ua, double ub, AreaInfo& o) {
     auto p = sh->p;
     switch (sh->gkind) {  // a medium answers for its boundary (constant_medium.rs:101-103)
         case MRT_SHAPE_SPHERE: {  // sphere.rs:72-87
@@ -1193,22 +1202,22 @@ __device__ void shape_generate(OP sh, D3 origin, double time, const Rng& g, Area
             }
             break;
         }
-        case MRT_SHAPE_XY_RECT: rect_generate<2>(p[0], p[1], p[2], p[3], p[4], p[5], origin, time, g, o); break;
-        case MRT_SHAPE_XZ_RECT: rect_generate<1>(p[0], p[1], p[2], p[3], p[4], p[5], origin, time, g, o); break;
-        case MRT_SHAPE_YZ_RECT: rect_generate<0>(p[0], p[1], p[2], p[3], p[4], p[5], origin, time, g, o); break;
+        case MRT_SHAPE_XY_RECT: rect_generate<2>(p[0], p[1], p[2], p[3], p[4], p[5], origin, time, ua, ub, o); break;
+        case MRT_SHAPE_XZ_RECT: rect_generate<1>(p[0], p[1], p[2], p[3], p[4], p[5], origin, time, ua, ub, o); break;
+        case MRT_SHAPE_YZ_RECT: rect_generate<0>(p[0], p[1], p[2], p[3], p[4], p[5], origin, time, ua, ub, o); break;
         default: {  // RenderBox, render_box.rs:157-181
             uint32_t face = rand_u32(g, 0, 3, MRT_DIM_LIGHT_FACE);
             D3 c{(p[0] + p[3]) / 2.0, (p[1] + p[4]) / 2.0, (p[2] + p[5]) / 2.0};
             D3 to_self = c - origin;
             if (face == 0) {
-                if (to_self.x >= 0.0) rect_generate<0>(p[1], p[4], p[2], p[5], p[0], -1.0, origin, time, g, o);
-                else rect_generate<0>(p[1], p[4], p[2], p[5], p[3], 1.0, origin, time, g, o);
+                if (to_self.x >= 0.0) rect_generate<0>(p[1], p[4], p[2], p[5], p[0], -1.0, origin, time, ua, ub, o);
+                else rect_generate<0>(p[1], p[4], p[2], p[5], p[3], 1.0, origin, time, ua, ub, o);
             } else if (face == 1) {
-                if (to_self.y >= 0.0) rect_generate<1>(p[0], p[3], p[2], p[5], p[1], -1.0, origin, time, g, o);
-                else rect_generate<1>(p[0], p[3], p[2], p[5], p[4], 1.0, origin, time, g, o);
+                if (to_self.y >= 0.0) rect_generate<1>(p[0], p[3], p[2], p[5], p[1], -1.0, origin, time, ua, ub, o);
+                else rect_generate<1>(p[0], p[3], p[2], p[5], p[4], 1.0, origin, time, ua, ub, o);
             } else {
-                if (to_self.z >= 0.0) rect_generate<2>(p[0], p[3], p[1], p[4], p[2], -1.0, origin, time, g, o);
-                else rect_generate<2>(p[0], p[3], p[1], p[4], p[5], 1.0, origin, time, g, o);
+                if (to_self.z >= 0.0) rect_generate<2>(p[0], p[3], p[1], p[4], p[2], -1.0, origin, time, ua, ub, o);
+                else rect_generate<2>(p[0], p[3], p[1], p[4], p[5], 1.0, origin, time, ua, ub, o);
             }
             break;
         }
@@ -1216,9 +1225,9 @@ __device__ void shape_generate(OP sh, D3 origin, double time, const Rng& g, Area
 }
 // Object::generate_ray_in_area, hittable.rs:289-312
 template <int FEAT, class OP>
-__device__ void object_generate(OP ob, D3 origin, double time, const Rng& g, AreaInfo& out) {
+__device__ void object_generate(OP ob, D3 origin, double time, const Rng& g, double ua, double ub, AreaInfo& out) {
     if (ob->identity) {
-        shape_generate<FEAT>(ob, origin, time, g, out);
+        shape_generate<FEAT>(ob, origin, time, g, ua, ub, out);
         // the reference still routes every vector through the (identity) inverse
         D3 o = out.to_area.o;
         out.to_area.d = (o + out.to_area.d) - o;
@@ -1227,7 +1236,7 @@ __device__ void object_generate(OP ob, D3 origin, double time, const Rng& g, Are
         return;
     }
     AreaInfo a;
-    shape_generate<FEAT>(ob, apply(&ob->to_object, origin), time, g, a);
+    shape_generate<FEAT>(ob, apply(&ob->to_object, origin), time, g, ua, ub, a);
     auto inv = &ob->to_world;
     out.end_point = apply(inv, a.end_point);
     out.to_area = xform_ray(inv, false, a.to_area);
@@ -1306,11 +1315,21 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
     REGION_BEGIN(gen);
     Onb uvw = onb_from_w(pdf_normal);
     uint32_t r = rand_u32(g, 0, 3, MRT_DIM_PDF_CHOICE);
+    // Every branch below starts with two uniforms (cosine lobe: r1, r2; light: the two coordinates on a
+    // flat light; sky: the first two coordinates of the first candidate, or the sun sample). They are
+    // drawn here for all lanes at once, each lane at the dimensions of its own branch, instead of
+    // three times for a third of the lanes.
+    bool has_sun = false;
+    if constexpr ((FEAT & FEAT_SKY) != 0) has_sun = sv.sun.has_sun != 0;
+    const uint64_t add_a = r == 0 ? rng_dim_addend(MRT_DIM_COS_R1)
+                                  : (r == 1 ? rng_dim_addend(MRT_DIM_LIGHT_A) : (has_sun ? rng_dim_addend(MRT_DIM_SUN_R) : rng_dim_addend(MRT_DIM_SKY)));
+    const uint64_t add_b = r == 0 ? rng_dim_addend(MRT_DIM_COS_R2)
+                                  : (r == 1 ? rng_dim_addend(MRT_DIM_LIGHT_B) : (has_sun ? rng_dim_addend(MRT_DIM_SUN_THETA) : rng_dim_addend(MRT_DIM_SKY + 1)));
+    const double ua = rng_f64_addend(g, add_a), ub = rng_f64_addend(g, add_b);
     D3 dir;
     double own;
     if (r == 0) {  // CosinePdf::generate, pdf.rs:45-60; random_cosine_direction, prelude.rs:145-153
-        double r1 = rand_scalar(g, 0.0, 1.0, MRT_DIM_COS_R1);
-        double r2 = rand_scalar(g, 0.0, 1.0, MRT_DIM_COS_R2);
+        double r1 = ua, r2 = ub;  // rand_scalar(0, 1) is the uniform itself
         double z = sqrt(1.0 - r2);
         double sr2 = sqrt(r2);
         double sphi, cphi;
@@ -1325,7 +1344,7 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
         // a one-entry list needs no draw (x % 1 == 0; draws are addressed by dimension)
         uint32_t idx = sv.n_lights == 1 ? 0u : rand_u32(g, 0, (uint32_t)sv.n_lights, MRT_DIM_LIGHT_INDEX);
         AreaInfo ai;
-        object_generate<(FEAT & ~(FEAT_OCTREE | FEAT_VOLUME))>(sv.lights + idx, hit_point, incoming_time, g, ai);
+        object_generate<(FEAT & ~(FEAT_OCTREE | FEAT_VOLUME))>(sv.lights + idx, hit_point, incoming_time, g, ua, ub, ai);
         D3 nd = normalize(ai.to_area.d);
         double light_cos = fabs(dot(nd, ai.normal));
         double dist_squared = dot(ai.direction, ai.direction);
@@ -1334,14 +1353,12 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
         dir = nd;
         REGION_END(st, ST_GEN_LIGHT, gen);
     } else {  // SkyPdf::generate, pdf.rs:154-193
-        bool has_sun = false;
-        if constexpr ((FEAT & FEAT_SKY) != 0) has_sun = sv.sun.has_sun != 0;
         if (!has_sun) {
-            dir = rand_unit_vec(g, MRT_DIM_SKY);
+            dir = rand_unit_vec(g, MRT_DIM_SKY, ua, ub);
             own = 4.0 * M_PI;
         } else if constexpr ((FEAT & FEAT_SKY) != 0) {
-            double rr = sqrt(rand_scalar(g, 0.0, 1.0, MRT_DIM_SUN_R));
-            double theta = rand_scalar(g, 0.0, 2.0 * M_PI, MRT_DIM_SUN_THETA);
+            double rr = sqrt(ua);                              // rand_scalar(0, 1)
+            double theta = ub * (2.0 * M_PI - 0.0) + 0.0;      // rand_scalar(0, 2 pi)
             rr = rr * sv.sun.radius;
             D3 svv = sun_direction(sv.sun);
             D3 k = normalize(cross(svv, D3{0.0, 0.0, 1.0}));
@@ -1817,7 +1834,7 @@ __global__ void __launch_bounds__(BLOCK) k_single_bounce(SceneView sv, RenderPar
             AreaInfo ai;
             ai.to_area = ray;
             ai.end_point = {0, 0, 0};
-            if (hit) object_generate<LF>(lights + i, pos_w, h.t, gi, ai);
+            if (hit) object_generate<LF>(lights + i, pos_w, h.t, gi, rng_f64(gi, MRT_DIM_LIGHT_A), rng_f64(gi, MRT_DIM_LIGHT_B), ai);
             HitD h2{0.0, -1, 0, {0.0, 0.0, 0.0}};
             bool hit2 = WAVE ? nearest_hit_wave<FEAT>(sv, ai.to_area, gi, hit, h2, st)
                              : (hit && nearest_hit_lane<FEAT>(sv, ai.to_area, gi, h2));
