@@ -175,6 +175,9 @@ def main():
         if world_size == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
             cb = cpu_baseline(info, W, H, args.cpu_spp, threads)
+            # the reference's own layout: eight worker threads over eight vertical strips (ray_tracer.rs:496-497)
+            ref8 = cpu_baseline(info, W, H, max(1, args.cpu_spp // 8), 8)
+            cb["reference_layout_8_threads"] = {k: ref8[k] for k in ("value", "unit", "cores", "seconds", "sample")}
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = out["value"] / cb["value"] if cb["value"] else None
         print(json.dumps(out), flush=True)
