@@ -378,7 +378,12 @@ enum mrt_shader { MRT_SHADER_RAYTRACING = 0, MRT_SHADER_DIFFUSE = 1, MRT_SHADER_
  *   "segments_per_launch"    1..64 segments per kernel launch (default 32)
  *   "compaction"             0/1 pack live paths in the drain phase (default 1)
  *   "traversal"              0 auto, 1 per-lane tree walk, 2 wave-synchronous
- *                            tree walk, 3 wave-synchronous walk over the leaf list
+ *                            tree walk, 3 wave-synchronous walk over the leaf list,
+ *                            4 candidate search (a spatial tree finds the leaves a
+ *                            ray can meet; the tree walk then runs over those
+ *                            leaves and their ancestors only; auto picks it for
+ *                            trees of more than 64 nodes; scenes with media, volume
+ *                            voxels or more than 1536 tree nodes fall back to 1)
  *   "trace_zero_throughput"  1: keep walking paths whose throughput is exactly
  *                            zero, as the reference does (same image, counters
  *                            match the reference's)

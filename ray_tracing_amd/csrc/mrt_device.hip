@@ -38,6 +38,10 @@ struct SceneView {
     int32_t n_objects;
     int32_t n_lights;
     int32_t trace_zero_throughput;
+    int32_t n_cand_nodes;  // > 0: the per-lane query runs the candidate search instead of the walk
+    int32_t n_cand_words;  // 32-node words of the candidate bit array in use
+    const DCandNode* cand_nodes;
+    const int32_t* cand_parent;
     const DObjRec* objects;  // one record per object (shape, transform, material)
     const DObjRec* lights;   // the light list, same record type
     const DTexture* textures;
@@ -63,6 +67,7 @@ struct Pool {
 // from the global counter with one atomic and serves its lanes from that range; what is left of
 // the range when a launch ends is kept per wave ([next, end) pairs) for the next launch.
 constexpr uint32_t WORK_CHUNK = 512;
+constexpr int BLOCK = 256;  // threads per workgroup of every kernel here
 
 enum : int { ST_REGEN = 0, ST_TRAVERSE, ST_LEAF, ST_SURFACE, ST_LAMBERT_GEN, ST_LIGHT_VALUE, ST_SHADE, ST_ACCUM, ST_TOTAL, ST_MEDIUM_TAIL, ST_CLAIM, ST_GEN_COS, ST_GEN_LIGHT, ST_GEN_SKY, ST_ISOTROPIC, ST_COUNT };
 struct Counters {
@@ -806,52 +811,130 @@ struct HitD {
 // re-testing the box against the updated bound, with a fresh medium draw (bvh.rs:224-232).
 //
 // Per-lane variant: every lane walks its own node sequence (large trees, incoherent rays).
+struct LaneWalk {
+    double closest;
+    int best_obj, best_sub;
+    D3 best_pos;
+    uint32_t medium_ordinal, oct_entry;
+};
+// One node visit of the walk: the node's box test against the running bound and, for a leaf that
+// passes, the object's intersection test(s). Returns whether the box test passed.
 template <int FEAT>
-__device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng& g, HitD& out) {
+__device__ __forceinline__ bool lane_visit(const SceneView& sv, const DNode& nd, const RayD& ray, D3 inv_d, const Rng& g,
+                                           LaneWalk& w) {
     const double t_min = (double)0.001f;
-    double closest = (double)FLT_MAX;
-    int best_obj = -1, best_sub = 0;
-    D3 best_pos{0.0, 0.0, 0.0};
-    uint32_t medium_ordinal = 0, oct_entry = 0;
+    const int obj = nd.object;
+    const int flags = nd.flags;
+    D3 mn{nd.bmin[0], nd.bmin[1], nd.bmin[2]};
+    D3 mx{nd.bmax[0], nd.bmax[1], nd.bmax[2]};
+    if constexpr ((FEAT & FEAT_SPHERE) != 0) {
+        if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(sv.objects + obj, t_min, w.closest, mn, mx);
+    }
+    if (!aabb_hit(mn, mx, ray, inv_d, t_min, w.closest)) return false;
+    if (obj >= 0) {
+        const DObjRec* ob = sv.objects + obj;
+        bool is_medium = false;
+        if constexpr ((FEAT & FEAT_MEDIUM) != 0) is_medium = ob->kind == MRT_SHAPE_CONSTANT_MEDIUM;
+        const int rounds = (flags & NODE_TWICE) ? 2 : 1;
+#pragma nounroll
+        for (int round = 0; round < rounds; ++round) {
+            if (round == 1 && !aabb_hit(mn, mx, ray, inv_d, t_min, w.closest)) break;
+            double t;
+            int sub;
+            if (object_hit<FEAT>(sv, ob, ray, inv_d, t_min, w.closest, g, MRT_DIM_MEDIUM + w.medium_ordinal, w.oct_entry, t, sub, w.best_pos)) {
+                w.closest = t, w.best_obj = obj, w.best_sub = sub;
+            }
+            if (is_medium) w.medium_ordinal++;
+        }
+    }
+    return true;
+}
+// Whether the ray's line over [0.001, FLT_MAX] can meet a node's box at the ray's time (all three
+// slabs jointly). An undefined slab bound (0 * inf: the ray runs inside a face plane) leaves that
+// axis open.
+__device__ __forceinline__ bool line_meets_box(const DCandNode* nd, const RayD& r, D3 inv_d) {
+    double lo = (double)0.001f, hi = (double)FLT_MAX;
+    const double o[3] = {r.o.x, r.o.y, r.o.z}, inv[3] = {inv_d.x, inv_d.y, inv_d.z};
+    const bool moving = nd->moving != 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double bl = nd->lo[a], bh = nd->hi[a];
+        if (moving) {
+            const double s0 = r.time * nd->vlo[a], s1 = r.time * nd->vhi[a];
+            bl += fmin(s0, s1), bh += fmax(s0, s1);
+        }
+        double t0 = (bl - o[a]) * inv[a], t1 = (bh - o[a]) * inv[a];
+        const bool undefined = t0 != t0 || t1 != t1;
+        double a0 = fmin(t0, t1), a1 = fmax(t0, t1);
+        if (!undefined) lo = fmax(lo, a0), hi = fmin(hi, a1);
+    }
+    return lo <= hi;
+}
+#define LDS_AS __attribute__((address_space(3)))
+// Candidate search for large trees (host side: build_candidate_tree). `bits` is this lane's
+// column of a [CAND_WORDS][BLOCK] bit array in LDS, one bit per tree node, all zero on entry and
+// on return. Phase 1 walks the spatial tree and marks every leaf whose tight box the ray's line
+// meets, together with the leaf's ancestors; phase 2 is the reference's walk over the marked
+// nodes (ascending index = pre-order), with the walk's own node code. Gives the walk's result.
+template <int FEAT>
+__device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, const Rng& g, HitD& out, LDS_AS uint32_t* bits) {
+    D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
+    {
+        int i = 0;
+        const int n = sv.n_cand_nodes;
+        while (i < n) {
+            const DCandNode* nd = sv.cand_nodes + i;
+            const int object = nd->object, skip = nd->skip;
+            if (!line_meets_box(nd, ray, inv_d)) {
+                i = skip;
+                continue;
+            }
+            for (int k = object; k >= 0; k = sv.cand_parent[k]) {
+                const uint32_t bit = 1u << (k & 31);
+                const uint32_t old = bits[(k >> 5) * BLOCK];
+                if (old & bit) break;  // this ancestor and all above it are marked already
+                bits[(k >> 5) * BLOCK] = old | bit;
+            }
+            i = i + 1;
+        }
+    }
+    LaneWalk w{(double)FLT_MAX, -1, 0, {0.0, 0.0, 0.0}, 0, 0};
+    const int words = sv.n_cand_words;
+    int resume = 0;  // nodes below this index lie in a subtree whose box test failed
+    for (int wd = 0; wd < words; ++wd) {
+        uint32_t m = bits[wd * BLOCK];
+        if (m == 0) continue;
+        bits[wd * BLOCK] = 0;
+        while (m) {
+            const int idx = wd * 32 + __ffs((int)m) - 1;
+            m &= m - 1;
+            if (idx < resume) continue;
+            const DNode nd = sv.nodes[idx];
+            if (!lane_visit<FEAT>(sv, nd, ray, inv_d, g, w)) resume = nd.skip;
+        }
+    }
+    out.t = w.closest;
+    out.obj = w.best_obj;
+    out.sub = w.best_sub;
+    out.pos = w.best_pos;
+    return w.best_obj >= 0;
+}
+template <int FEAT>
+__device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng& g, HitD& out, LDS_AS uint32_t* bits = nullptr) {
+    if (sv.n_cand_nodes > 0 && bits) return nearest_hit_candidates<FEAT>(sv, ray, g, out, bits);
+    LaneWalk w{(double)FLT_MAX, -1, 0, {0.0, 0.0, 0.0}, 0, 0};
     D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
     int i = 0;
     const int n = sv.n_nodes;
     while (i < n) {
         const DNode nd = sv.nodes[i];
-        const int obj = nd.object;
-        const int flags = nd.flags;
-        D3 mn{nd.bmin[0], nd.bmin[1], nd.bmin[2]};
-        D3 mx{nd.bmax[0], nd.bmax[1], nd.bmax[2]};
-        if constexpr ((FEAT & FEAT_SPHERE) != 0) {
-            if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(sv.objects + obj, t_min, closest, mn, mx);
-        }
-        if (!aabb_hit(mn, mx, ray, inv_d, t_min, closest)) {
-            i = nd.skip;
-            continue;
-        }
-        if (obj >= 0) {
-            const DObjRec* ob = sv.objects + obj;
-            bool is_medium = false;
-            if constexpr ((FEAT & FEAT_MEDIUM) != 0) is_medium = ob->kind == MRT_SHAPE_CONSTANT_MEDIUM;
-            const int rounds = (flags & NODE_TWICE) ? 2 : 1;
-#pragma nounroll
-            for (int round = 0; round < rounds; ++round) {
-                if (round == 1 && !aabb_hit(mn, mx, ray, inv_d, t_min, closest)) break;
-                double t;
-                int sub;
-                if (object_hit<FEAT>(sv, ob, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, oct_entry, t, sub, best_pos)) {
-                    closest = t, best_obj = obj, best_sub = sub;
-                }
-                if (is_medium) medium_ordinal++;
-            }
-        }
-        i = i + 1;
+        i = lane_visit<FEAT>(sv, nd, ray, inv_d, g, w) ? i + 1 : nd.skip;
     }
-    out.t = closest;
-    out.obj = best_obj;
-    out.sub = best_sub;
-    out.pos = best_pos;
-    return best_obj >= 0;
+    out.t = w.closest;
+    out.obj = w.best_obj;
+    out.sub = w.best_sub;
+    out.pos = w.best_pos;
+    return w.best_obj >= 0;
 }
 
 // Wave-synchronous variant for small trees: the whole wave visits the nodes in pre-order with
@@ -1583,7 +1666,7 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
 // path; with WAVE the traversal is wave-synchronous and every lane of the wave must call this.
 template <bool WAVE, int FEAT>
 __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, bool live, F3& radiance,
-                             uint32_t& rays, uint32_t& light_queries, Stamps& st) {
+                             uint32_t& rays, uint32_t& light_queries, Stamps& st, LDS_AS uint32_t* cand_bits) {
     radiance = {0.f, 0.f, 0.f};
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     bool hit;
@@ -1591,7 +1674,7 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
     if (WAVE) {
         hit = nearest_hit_wave<FEAT>(sv, ray, g, live, h, st);
     } else {
-        hit = live && nearest_hit_lane<FEAT>(sv, ray, g, h);
+        hit = live && nearest_hit_lane<FEAT>(sv, ray, g, h, cand_bits);
     }
     REGION_END(st, ST_TRAVERSE, trav);
     if (!live) return false;
@@ -1603,7 +1686,13 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
 }
 
 // ============================================================== kernels
-constexpr int BLOCK = 256;
+// This lane's column of the workgroup's candidate bit array (nearest_hit_candidates), cleared.
+__device__ __forceinline__ LDS_AS uint32_t* candidate_bits(const SceneView& sv) {
+    __shared__ uint32_t cand_words[CAND_WORDS * BLOCK];
+    LDS_AS uint32_t* bits = (LDS_AS uint32_t*)cand_words + threadIdx.x;
+    for (int w = 0; w < sv.n_cand_words; ++w) bits[w * BLOCK] = 0;
+    return bits;
+}
 // Waves per SIMD the segment kernel is compiled for (512 / waves registers per lane). Measured:
 // three waves hide the scene-record and pool latencies best as long as the kernel fits 168
 // registers without heavy spilling; the wave-synchronous kernels of the large feature sets
@@ -1650,6 +1739,8 @@ __global__ void __launch_bounds__(BLOCK, seg_waves(WAVE, FEAT)) k_segments(Scene
     chunk_end = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(chunk_end >> 32)) << 32) |
                 __builtin_amdgcn_readfirstlane((uint32_t)chunk_end);
     bool dry = false;  // the global counter has run past the end of the work
+    LDS_AS uint32_t* cand_bits = nullptr;
+    if constexpr (!WAVE) cand_bits = candidate_bits(sv);
     Stamps st{};
     REGION_BEGIN(total);
     for (uint32_t step = 0; step < rp.steps; ++step) {
@@ -1711,7 +1802,7 @@ __global__ void __launch_bounds__(BLOCK, seg_waves(WAVE, FEAT)) k_segments(Scene
         if (WAVE && !__any(live)) break;
         Rng g{key, (uint32_t)(live ? seg : 0)};
         F3 radiance;
-        bool cont = path_segment<WAVE, FEAT>(sv, ray, thr, g, live, radiance, rays, light_queries, st);
+        bool cont = path_segment<WAVE, FEAT>(sv, ray, thr, g, live, radiance, rays, light_queries, st, cand_bits);
         REGION_BEGIN(acc);
         if (live) {
             seg++;
@@ -1915,7 +2006,9 @@ __global__ void __launch_bounds__(BLOCK) k_trace_rays(SceneView sv, const double
     Rng g{path_key(seed, (uint64_t)i, 0), 0};
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     Stamps st{};
-    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g, live, h, st) : (live && nearest_hit_lane<FEAT>(sv, ray, g, h));
+    LDS_AS uint32_t* cand_bits = nullptr;
+    if constexpr (!WAVE) cand_bits = candidate_bits(sv);
+    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g, live, h, st) : (live && nearest_hit_lane<FEAT>(sv, ray, g, h, cand_bits));
     if (!live) return;
     D3 n_w{0, 0, 0}, p_w{0, 0, 0};
     if (hit) {
@@ -2001,7 +2094,7 @@ struct mrt_scene {
     int64_t opt_trace_zero = 0;
     int64_t opt_compact = 1;
     int64_t opt_shader = MRT_SHADER_RAYTRACING;
-    int64_t opt_traversal = 0;  // 0 auto, 1 per-lane, 2 wave-synchronous over the tree, 3 over the leaf list
+    int64_t opt_traversal = 0;  // 0 auto, 1 per-lane, 2 wave-synchronous over the tree, 3 over the leaf list, 4 candidates
     const DNodeRec* dev_node_recs = nullptr;
     const DNodeRec* dev_leaf_recs = nullptr;
     int features = 0;           // FEAT_* bits the scene needs
@@ -2047,17 +2140,20 @@ static int scene_features(const FlatScene& f) {
 // LEAF_LIST_MAX leaves the walk visits the leaf list instead of the tree.
 constexpr int WAVE_SYNC_MAX_NODES = 64;
 constexpr int LEAF_LIST_MAX = 16;
-enum : int { TRAV_LANE = 1, TRAV_WAVE_TREE = 2, TRAV_WAVE_LEAVES = 3 };
+enum : int { TRAV_LANE = 1, TRAV_WAVE_TREE = 2, TRAV_WAVE_LEAVES = 3, TRAV_CANDIDATES = 4 };
 static int traversal_mode(const mrt_scene* sc) {
     const bool have_list = !sc->flat.leaf_recs.empty();
+    const bool have_cand = !sc->flat.cand_nodes.empty();
     if (sc->opt_traversal == TRAV_LANE || sc->opt_traversal == TRAV_WAVE_TREE) return (int)sc->opt_traversal;
     if (sc->opt_traversal == TRAV_WAVE_LEAVES) return have_list ? TRAV_WAVE_LEAVES : TRAV_WAVE_TREE;
-    if ((int)sc->flat.node_object.size() > WAVE_SYNC_MAX_NODES) return TRAV_LANE;
+    if (sc->opt_traversal == TRAV_CANDIDATES) return have_cand ? TRAV_CANDIDATES : TRAV_LANE;
+    if ((int)sc->flat.node_object.size() > WAVE_SYNC_MAX_NODES) return have_cand ? TRAV_CANDIDATES : TRAV_LANE;
     return have_list && (int)sc->flat.leaf_recs.size() <= LEAF_LIST_MAX ? TRAV_WAVE_LEAVES : TRAV_WAVE_TREE;
 }
 // Scene view for one launch: points the wave-synchronous walk at the tree or at the leaf list.
 static SceneView view_for(const mrt_scene* sc, int mode) {
     SceneView v = sc->view;
+    if (mode != TRAV_CANDIDATES) v.n_cand_nodes = 0, v.n_cand_words = 0;
     if (mode == TRAV_WAVE_LEAVES) {
         v.node_recs = sc->dev_leaf_recs;
         v.n_wave_nodes = (int32_t)sc->flat.leaf_recs.size();
@@ -2080,11 +2176,14 @@ int upload_scene(mrt_scene* sc) {
     UP(f.nodes, nodes)
     if ((rc = m.upload(f.node_recs, &sc->dev_node_recs)) != MRT_OK) return rc;
     if ((rc = m.upload(f.leaf_recs, &sc->dev_leaf_recs)) != MRT_OK) return rc;
+    UP(f.cand_nodes, cand_nodes) UP(f.cand_parent, cand_parent)
     UP(f.obj_recs, objects) UP(f.light_recs, lights)
     UP(f.textures, textures) UP(f.images, images) UP(f.image_pool, image_pool) UP(f.perlins, perlins)
     UP(f.octrees, octrees) UP(f.oct_nodes, oct_nodes) UP(f.oct_voxels, oct_voxels)
 #undef UP
     v.n_nodes = (int32_t)f.node_object.size();
+    v.n_cand_nodes = (int32_t)f.cand_nodes.size();
+    v.n_cand_words = f.cand_nodes.empty() ? 0 : (int32_t)((f.node_object.size() + 31) / 32);
     v.n_objects = (int32_t)f.objects.size();
     v.n_lights = (int32_t)f.lights.size();
     v.cam = f.camera;
@@ -2149,7 +2248,7 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     const int trav = traversal_mode(sc);
     SceneView view = view_for(sc, trav);
     view.trace_zero_throughput = (int32_t)sc->opt_trace_zero;
-    const bool wave_sync = trav != TRAV_LANE;
+    const bool wave_sync = trav != TRAV_LANE && trav != TRAV_CANDIDATES;
 
     hipEvent_t ev_begin, ev_end, ek0, ek1;
     HIP_TRY(hipEventCreate(&ev_begin));
@@ -2374,7 +2473,7 @@ int mrt_scene_set_option(mrt_scene* scene, const char* name, int64_t value) {
             return set_error(MRT_ERR_INVALID_ARGUMENT, "shader must be one of MRT_SHADER_*");
         scene->opt_shader = value;
     } else if (n == "traversal") {
-        if (value < 0 || value > 3) return set_error(MRT_ERR_INVALID_ARGUMENT, "traversal must be 0..3");
+        if (value < 0 || value > 4) return set_error(MRT_ERR_INVALID_ARGUMENT, "traversal must be 0..4");
         scene->opt_traversal = value;
     } else {
         return set_error(MRT_ERR_INVALID_ARGUMENT, "unknown option: " + n);
@@ -2430,7 +2529,7 @@ int mrt_trace_rays(mrt_scene* scene, const double* rays, size_t n, uint64_t seed
     {
         const dim3 grid(((uint32_t)n + BLOCK - 1) / BLOCK), block(BLOCK);
         const int trav = traversal_mode(scene);
-        const bool ws = trav != TRAV_LANE;
+        const bool ws = trav != TRAV_LANE && trav != TRAV_CANDIDATES;
         const SceneView view = view_for(scene, trav);
         dispatch_feat(scene->features, KernelFeats{}, [&](auto feat) {
             constexpr int FT = decltype(feat)::value;

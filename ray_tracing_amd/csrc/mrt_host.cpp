@@ -272,6 +272,145 @@ void emit_device(const FlatScene& s, const TreeNode* n, FlatScene* out) {
     out->node_skip[me] = (int32_t)out->node_object.size();
 }
 
+// ---- candidate search for large trees
+// The reference's tree splits index ranges of the object list, not space (bvh.rs:254-277 sorts a
+// copy, the leaves keep the list positions), so the boxes of a many-object scene overlap almost
+// everywhere and a ray visits most of the tree. The walk's result does not need that work: a leaf
+// can change the running nearest hit only if the ray meets the leaf's shape. So a lane first
+// collects, through a spatial tree over tight world boxes, the leaves whose shape the ray's line
+// can meet at all (any order, no nearest-hit bound), marks them and their ancestors, and then
+// runs the reference's walk over the marked nodes only: same order, same box tests against the
+// same running bound, same leaf code. An unmarked subtree holds no leaf the ray can hit, so
+// leaving it out changes nothing. Shapes that draw random numbers (media, volume octrees) number
+// their draws by visit, which leaving out visits would change: such scenes do not qualify.
+struct CandItem {
+    Box a;          // box at ray time 0
+    double v[3];    // velocity of the box per unit of ray time
+    Box sah;        // box over typical ray times, for the split heuristic only
+    int32_t node;
+};
+// Tight world box of an object as a function of the ray's time tau: a.mn + tau * v .. a.mx + tau * v.
+bool tight_box(const FlatScene& s, const DObject& o, CandItem* it) {
+    const DShape& sh = s.shapes[(size_t)o.shape];
+    Box sb;
+    double v[3] = {0.0, 0.0, 0.0};
+    if (sh.kind == MRT_SHAPE_MOVING_SPHERE) {
+        // centre(tau) = c0 + (tau - t0) / (t1 - t0) * (c1 - c0) = (c0 - t0 * v) + tau * v
+        const double* p = sh.p;
+        const double dt = p[8] - p[7], r = std::fabs(p[0]);
+        for (int i = 0; i < 3; ++i) {
+            v[i] = (p[4 + i] - p[1 + i]) / dt;
+            double c = p[1 + i] - p[7] * v[i];
+            if (!std::isfinite(v[i]) || !std::isfinite(c)) return false;
+            sb.mn[i] = c - r, sb.mx[i] = c + r;
+        }
+    } else {
+        if (!shape_box(s, o.shape, 0.0, 0.0, &sb)) return false;
+        for (int i = 0; i < 3; ++i)
+            if (sb.mn[i] > sb.mx[i]) std::swap(sb.mn[i], sb.mx[i]);  // a negative radius turns the box inside out
+    }
+    Box& b = it->a;
+    for (int i = 0; i < 3; ++i) b.mn[i] = INFINITY, b.mx[i] = -INFINITY;
+    for (int k = 0; k < 8; ++k) {
+        double c[3] = {(k & 1) ? sb.mx[0] : sb.mn[0], (k & 2) ? sb.mx[1] : sb.mn[1], (k & 4) ? sb.mx[2] : sb.mn[2]}, w[3];
+        apply(o.to_world, c, w);
+        for (int i = 0; i < 3; ++i) b.mn[i] = std::min(b.mn[i], w[i]), b.mx[i] = std::max(b.mx[i], w[i]);
+    }
+    for (int i = 0; i < 3; ++i) {  // the linear part of the transform applied to the velocity
+        it->v[i] = (o.to_world.r[i][0] * v[0] + o.to_world.r[i][1] * v[1]) + o.to_world.r[i][2] * v[2];
+        if (!std::isfinite(b.mn[i]) || !std::isfinite(b.mx[i]) || !std::isfinite(it->v[i])) return false;
+        double m = 1e-9 * (1.0 + std::max(std::fabs(b.mn[i]), std::fabs(b.mx[i])));  // margin against rounding
+        b.mn[i] -= m, b.mx[i] += m;
+        const double tau = 2.0;  // bounce distances of a few units are the common ray times
+        it->sah.mn[i] = b.mn[i] + std::min(0.0, tau * it->v[i]);
+        it->sah.mx[i] = b.mx[i] + std::max(0.0, tau * it->v[i]);
+    }
+    return true;
+}
+double half_area(const Box& b) {
+    double d[3] = {b.mx[0] - b.mn[0], b.mx[1] - b.mn[1], b.mx[2] - b.mn[2]};
+    return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+}
+void grow(Box* a, const Box& b) {
+    for (int i = 0; i < 3; ++i) a->mn[i] = std::min(a->mn[i], b.mn[i]), a->mx[i] = std::max(a->mx[i], b.mx[i]);
+}
+const Box kEmptyBox{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
+// Surface-area-heuristic split by full sweeps over the three centroid orders; emits pre-order nodes.
+void build_candidate_nodes(std::vector<CandItem>& items, size_t lo, size_t hi, std::vector<DCandNode>* out) {
+    const size_t me = out->size();
+    out->push_back(DCandNode{});
+    DCandNode nd{};
+    nd.object = -1;
+    for (int a = 0; a < 3; ++a) nd.lo[a] = INFINITY, nd.hi[a] = -INFINITY, nd.vlo[a] = INFINITY, nd.vhi[a] = -INFINITY;
+    for (size_t i = lo; i < hi; ++i)
+        for (int a = 0; a < 3; ++a) {
+            nd.lo[a] = std::min(nd.lo[a], items[i].a.mn[a]), nd.hi[a] = std::max(nd.hi[a], items[i].a.mx[a]);
+            nd.vlo[a] = std::min(nd.vlo[a], items[i].v[a]), nd.vhi[a] = std::max(nd.vhi[a], items[i].v[a]);
+        }
+    for (int a = 0; a < 3; ++a) {
+        if (nd.vlo[a] != 0.0 || nd.vhi[a] != 0.0) nd.moving = 1;
+        // widen the velocity interval a little: tau * v is rounded differently from the shape's own centre formula
+        nd.vlo[a] -= 1e-9 * std::fabs(nd.vlo[a]), nd.vhi[a] += 1e-9 * std::fabs(nd.vhi[a]);
+    }
+    if (hi - lo == 1) {
+        nd.object = items[lo].node;
+    } else {
+        const size_t n = hi - lo;
+        double best = INFINITY;
+        int best_axis = 0;
+        size_t best_split = n / 2;
+        std::vector<double> right(n);
+        auto by_centre = [](int axis) {
+            return [axis](const CandItem& x, const CandItem& y) {
+                return x.sah.mn[axis] + x.sah.mx[axis] < y.sah.mn[axis] + y.sah.mx[axis];
+            };
+        };
+        for (int axis = 0; axis < 3; ++axis) {
+            std::sort(items.begin() + (long)lo, items.begin() + (long)hi, by_centre(axis));
+            Box acc = kEmptyBox;
+            for (size_t i = n; i-- > 1;) {
+                grow(&acc, items[lo + i].sah);
+                right[i] = half_area(acc);
+            }
+            acc = kEmptyBox;
+            for (size_t i = 1; i < n; ++i) {
+                grow(&acc, items[lo + i - 1].sah);
+                double cost = half_area(acc) * (double)i + right[i] * (double)(n - i);
+                if (cost < best) best = cost, best_axis = axis, best_split = i;
+            }
+        }
+        std::sort(items.begin() + (long)lo, items.begin() + (long)hi, by_centre(best_axis));
+        build_candidate_nodes(items, lo, lo + best_split, out);
+        build_candidate_nodes(items, lo + best_split, hi, out);
+    }
+    nd.skip = (int32_t)out->size();
+    (*out)[me] = nd;
+}
+void build_candidate_tree(FlatScene* s) {
+    if (s->nodes.size() > (size_t)CAND_MAX_NODES) return;
+    std::vector<CandItem> items;
+    for (size_t i = 0; i < s->nodes.size(); ++i) {
+        const DNode& nd = s->nodes[i];
+        if (nd.object < 0) continue;
+        const DObject& ob = s->objects[(size_t)nd.object];
+        if ((nd.flags & NODE_TWICE) || shape_is_stochastic(*s, ob.shape)) return;
+        CandItem it;
+        if (!tight_box(*s, ob, &it)) return;
+        it.node = (int32_t)i;
+        items.push_back(it);
+    }
+    if (items.empty()) return;
+    build_candidate_nodes(items, 0, items.size(), &s->cand_nodes);
+    // parents in the pre-order node array: a node's subtree ends at its skip link
+    s->cand_parent.assign(s->nodes.size(), -1);
+    std::vector<int32_t> open;
+    for (size_t i = 0; i < s->nodes.size(); ++i) {
+        while (!open.empty() && s->nodes[(size_t)open.back()].skip <= (int32_t)i) open.pop_back();
+        s->cand_parent[i] = open.empty() ? -1 : open.back();
+        if (s->nodes[i].object < 0) open.push_back((int32_t)i);
+    }
+}
+
 int fail(std::string* err, int code, const std::string& msg) {
     if (err) *err = msg;
     return code;
@@ -599,6 +738,7 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
                 }
             }
         }
+        build_candidate_tree(&s);
         bool dynamic = false;
         for (const DNodeRec& r : s.node_recs) dynamic = dynamic || (r.flags & NODE_DYNAMIC_BOX);
         if (!dynamic) {

@@ -80,6 +80,10 @@ enum : int32_t {
     NODE_TWICE = 2         // span-1 leaf pair folded into one node; evaluate the object twice (bvh.rs:224-232)
 };
 
+// Largest tree (nodes) the candidate search handles: one bit per node and lane in LDS.
+constexpr int CAND_WORDS = 48;
+constexpr int CAND_MAX_NODES = CAND_WORDS * 32;
+
 // Device BVH node of the per-lane walk: one 64-byte line per node.
 struct DNode {
     double bmin[3], bmax[3];
@@ -89,6 +93,21 @@ struct DNode {
     int32_t pad;
 };
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
+
+// Node of the spatial tree of the candidate search. Its box at ray time tau is
+// [lo + min(tau * vlo, tau * vhi), hi + max(tau * vlo, tau * vhi)]: a MovingSphere's centre is
+// linear in the ray's time (sphere.rs:139-142), and scattered rays carry arbitrary times
+// (ray_tracer.rs:242,261 set time = hit t), so the bound has to hold for every tau.
+struct DCandNode {
+    double lo[3], hi[3];
+    int32_t object;  // leaf: index of the leaf it stands for in FlatScene::nodes; inner: -1
+    int32_t skip;
+    int32_t moving;  // 0: vlo = vhi = 0
+    int32_t pad;
+    double vlo[3], vhi[3];
+    double pad2[2];
+};
+static_assert(sizeof(DCandNode) == 128, "DCandNode must be 128 bytes");
 
 // One self-contained record per device BVH node for the wave-synchronous walk: everything the
 // box test and the leaf's intersection test need, so a node costs one batch of scalar loads
@@ -163,6 +182,11 @@ struct FlatScene {
     // Empty when a leaf box depends on the query (NODE_DYNAMIC_BOX).
     std::vector<DNodeRec> leaf_recs;
     std::vector<DObjRec> obj_recs, light_recs;
+    // Candidate search for large trees (see build_candidate_tree): a spatial tree over tight boxes of
+    // the leaves of `nodes`, in pre-order with skip links, and the parent of every node of `nodes`
+    // (-1 for the root). Empty when the scene does not qualify.
+    std::vector<DCandNode> cand_nodes;
+    std::vector<int32_t> cand_parent;
     bool has_medium = false;
 };
 

@@ -1,0 +1,109 @@
+"""The candidate search (traversal 4) must return exactly what the tree walk (traversal 1) returns:
+same object, same t, bit for bit, for every ray and every ray time, and the same image."""
+import numpy as np
+import pytest
+
+from ray_tracing_amd import ParallelImage, RayTracer
+from ray_tracing_amd import scene as S
+from tests.helpers import scene_by_name
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_render(rt, w, h, spp):
+    img = ParallelImage.new_black(w, h)
+    st = rt.trace_part(img.split(1)[0], spp, first_sample=0)
+    return img.buffer, st
+
+
+def crowded_scene(seed, n):
+    """n solids scattered over a ground sphere: static and moving spheres (one with a negative radius), rotated
+    boxes and rects; time ranges of the movers differ per object."""
+    rng = np.random.default_rng(seed)
+    col = lambda: tuple(float(np.float32(c)) for c in rng.uniform(0.1, 0.9, 3))
+    objects = [S.Object(S.Sphere(1000.0, (0.0, -1000.0, 0.0), S.Lambertian(S.SolidColor((0.5, 0.5, 0.5)))))]
+    for i in range(n):
+        c = np.array([rng.uniform(-12, 12), rng.uniform(0.2, 1.5), rng.uniform(-12, 12)])
+        mat = [S.Lambertian(S.SolidColor(col())), S.Metal(S.SolidColor(col()), float(rng.uniform(0, 0.6))),
+               S.Dielectric(1.5, (1.0, 1.0, 1.0))][int(rng.integers(0, 3))]
+        k = rng.integers(0, 10)
+        tr = S.Transform.identity()
+        if k <= 3:
+            shape = S.Sphere(float(rng.uniform(0.15, 0.5)), tuple(c), mat)
+        elif k <= 6:
+            t0 = float(rng.uniform(-1.0, 0.5))
+            shape = S.MovingSphere(tuple(c), tuple(c + rng.uniform(-0.6, 0.6, 3)), t0, t0 + float(rng.uniform(0.3, 2.0)),
+                                   float(rng.uniform(0.15, 0.5)), mat)
+            if rng.random() < 0.3:
+                tr = tr.translate(tuple(rng.uniform(-1, 1, 3))).rotate_y(float(rng.uniform(-50, 50)))
+        elif k == 7:
+            shape = S.RenderBox(tuple(c - 0.3), tuple(c + rng.uniform(0.2, 0.6, 3)), mat)
+            tr = tr.rotate_y(float(rng.uniform(-45, 45)))
+        elif k == 8:
+            shape = S.XZRect(c[0] - 0.5, c[0] + 0.5, c[2] - 0.5, c[2] + 0.5, float(c[1]), mat, False)
+            tr = tr.rotate_x(float(rng.uniform(-30, 30)))
+        else:
+            shape = S.Sphere(-float(rng.uniform(0.15, 0.4)), tuple(c), mat)
+        objects.append(S.Object(shape, tr))
+    cam = S.CameraInfo(1.0, 35.0, (16.0, 4.0, 5.0), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0), 0.01, 14.0, 0.0, 1.0)
+    return S.WorldInfo(objects, [], S.Sky(1.0), cam, bvh_seed=seed)
+
+
+def path_like_rays(rt, W, H, n, seed):
+    """Camera rays plus three generations of rays leaving the hit points in random directions, with the
+    times scattered rays carry (time = hit t, ray_tracer.rs:242,261) and some arbitrary ones."""
+    rng = np.random.default_rng(seed)
+    px = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], axis=1).astype(np.int32)
+    cur = rt.world.camera_rays(W, H, px, seed, 0)
+    out = [cur]
+    rt.world.set_option("traversal", 1)
+    for _ in range(3):
+        o, t, nrm, pos, ff = rt.world.trace_rays(cur, seed=seed)
+        hit = o >= 0
+        nxt = cur[hit].copy()
+        nxt[:, 0:3] = pos[hit]
+        nxt[:, 3:6] = rng.normal(size=(len(nxt), 3))
+        nxt[:, 6] = np.where(rng.random(len(nxt)) < 0.8, t[hit], rng.uniform(-3.0, 40.0, len(nxt)))
+        out.append(nxt)
+        cur = nxt
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("seed,n", [(1, 70), (2, 300), (3, 550), (4, 900)])
+def test_candidate_search_equals_tree_walk(seed, n):
+    rt = RayTracer(crowded_scene(seed, n), device=0, seed=seed)
+    rays = path_like_rays(rt, 320, 180, 60000, seed)
+    rt.world.set_option("traversal", 1)
+    o1, t1, n1, p1, f1 = rt.world.trace_rays(rays, seed=seed)
+    rt.world.set_option("traversal", 4)
+    o4, t4, n4, p4, f4 = rt.world.trace_rays(rays, seed=seed)
+    assert (o1 >= 0).sum() > len(rays) // 4
+    assert (o1 == o4).all() and (t1 == t4).all() and (n1 == n4).all() and (f1 == f4).all()
+    rt.world.set_option("traversal", 1)
+    a, sa = gpu_render(rt, 160, 90, 4)
+    rt.world.set_option("traversal", 4)
+    b, sb = gpu_render(rt, 160, 90, 4)
+    assert sa.rays == sb.rays
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)   # f32 atomic adds: order-dependent last bits
+
+
+def test_random_scene_image_is_the_walks_image():
+    """The reference's random_scene: 369 MovingSpheres whose leaf boxes depend on the running bound."""
+    rt = RayTracer(scene_by_name("Random Scene"), device=0, seed=4)
+    rt.world.set_option("traversal", 1)
+    a, sa = gpu_render(rt, 200, 112, 8)
+    rt.world.set_option("traversal", 0)   # auto picks the candidate search for a tree of this size
+    b, sb = gpu_render(rt, 200, 112, 8)
+    assert sa.rays == sb.rays and sa.paths == sb.paths
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_scenes_that_do_not_qualify_fall_back():
+    """Media draw random numbers per visit: traversal 4 then runs the per-lane walk."""
+    rt = RayTracer(scene_by_name("Cornell Smoke"), device=0, seed=4)
+    rt.world.set_option("traversal", 1)
+    a, sa = gpu_render(rt, 64, 64, 4)
+    rt.world.set_option("traversal", 4)
+    b, sb = gpu_render(rt, 64, 64, 4)
+    assert sa.rays == sb.rays
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)

@@ -148,7 +148,8 @@ def test_random_scene_parity(seed):
     assert off.mean() < 5e-3, f"{int(off.sum())} of {W * H} pixels differ"
     assert abs(int(st.rays) - int(rst.rays)) <= max(60, rst.rays // 500)
     # both wave-synchronous walks and the per-lane walk agree with each other on the same rays
-    for mode in (1, 2, 3):
+    # (4: candidate search where the scene qualifies, else the per-lane walk again)
+    for mode in (1, 2, 3, 4):
         rt.world.set_option("traversal", mode)
         om, tm, _, _, _ = rt.world.trace_rays(rays, seed=seed)
         assert (om == og).all() and (tm == tg).all()
