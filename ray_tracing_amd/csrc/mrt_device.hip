@@ -40,8 +40,10 @@ struct SceneView {
     int32_t trace_zero_throughput;
     int32_t n_cand_nodes;  // > 0: the per-lane query runs the candidate search instead of the walk
     int32_t n_cand_words;  // 32-node words of the candidate bit array in use
-    const DCandNode* cand_nodes;
-    const int32_t* cand_parent;
+    const DCand4* cand_nodes;
+    const int32_t* cand_chain;
+    int32_t n_cand_depth;
+    int32_t pad_cand;
     const DObjRec* objects;  // one record per object (shape, transform, material)
     const DObjRec* lights;   // the light list, same record type
     const DTexture* textures;
@@ -69,7 +71,7 @@ struct Pool {
 constexpr uint32_t WORK_CHUNK = 512;
 constexpr int BLOCK = 256;  // threads per workgroup of every kernel here
 
-enum : int { ST_REGEN = 0, ST_TRAVERSE, ST_LEAF, ST_SURFACE, ST_LAMBERT_GEN, ST_LIGHT_VALUE, ST_SHADE, ST_ACCUM, ST_TOTAL, ST_MEDIUM_TAIL, ST_CLAIM, ST_GEN_COS, ST_GEN_LIGHT, ST_GEN_SKY, ST_ISOTROPIC, ST_COUNT };
+enum : int { ST_REGEN = 0, ST_TRAVERSE, ST_LEAF, ST_SURFACE, ST_LAMBERT_GEN, ST_LIGHT_VALUE, ST_SHADE, ST_ACCUM, ST_TOTAL, ST_MEDIUM_TAIL, ST_CLAIM, ST_GEN_COS, ST_GEN_LIGHT, ST_GEN_SKY, ST_ISOTROPIC, ST_CAND_SEARCH, ST_COUNT };
 struct Counters {
     unsigned long long work_next;
     unsigned long long rays;
@@ -79,6 +81,7 @@ struct Counters {
     unsigned long long held;  // work items claimed by waves but not started when the launch ended
     unsigned long long stamps[ST_COUNT];  // diagnostic build only
     unsigned long long stamp_lanes[ST_COUNT];
+    unsigned long long stamp_counts[4];
 };
 
 // Diagnostic build (-DMRT_STAMPS): wave-level cycle shares of the segment kernel's regions.
@@ -88,7 +91,9 @@ struct Counters {
 struct Stamps {
     unsigned long long acc[ST_COUNT];
     unsigned long long lanes[ST_COUNT];  // cycles x active lanes (lane utilisation of the region)
+    unsigned int count[4];               // per-lane event counts of the candidate search
 };
+#define STAMP_COUNT(st, i) ((st).count[i]++)
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -105,6 +110,7 @@ __device__ __forceinline__ void stamp_add(Stamps& st, int i, unsigned long long 
 #define REGION_END(st, i, name) stamp_add(st, i, name##_t0)
 #else
 struct Stamps {};
+#define STAMP_COUNT(st, i) ((void)0)
 #define REGION_BEGIN(name) ((void)0)
 #define REGION_END(st, i, name) ((void)0)
 #endif
@@ -849,69 +855,118 @@ __device__ __forceinline__ bool lane_visit(const SceneView& sv, const DNode& nd,
     }
     return true;
 }
-// Whether the ray's line over [0.001, FLT_MAX] can meet a node's box at the ray's time (all three
-// slabs jointly). An undefined slab bound (0 * inf: the ray runs inside a face plane) leaves that
-// axis open.
-__device__ __forceinline__ bool line_meets_box(const DCandNode* nd, const RayD& r, D3 inv_d) {
+// Per-ray constants of the candidate search's slab tests: t = bound * inv - origin * inv.
+struct CandRay {
+    double inv[3], oi[3];
+    double tau;
+    int neg;  // tau < 0: selects the velocity bounds that give the lower / upper corner
+};
+// Whether the ray's line over [0.001, FLT_MAX] can meet the box of child k at the ray's time (all
+// three slabs jointly). Rays with a zero or non-finite direction component never get here.
+__device__ __forceinline__ bool line_meets_child(const DCand4* nd, int k, bool moving, const CandRay& r) {
     double lo = (double)0.001f, hi = (double)FLT_MAX;
-    const double o[3] = {r.o.x, r.o.y, r.o.z}, inv[3] = {inv_d.x, inv_d.y, inv_d.z};
-    const bool moving = nd->moving != 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        double bl = nd->lo[a], bh = nd->hi[a];
+        double bl = nd->lo[a][k], bh = nd->hi[a][k];
         if (moving) {
-            const double s0 = r.time * nd->vlo[a], s1 = r.time * nd->vhi[a];
-            bl += fmin(s0, s1), bh += fmax(s0, s1);
+            bl = fma(r.tau, nd->v_for_lo[r.neg][a][k], bl);
+            bh = fma(r.tau, nd->v_for_hi[r.neg][a][k], bh);
         }
-        double t0 = (bl - o[a]) * inv[a], t1 = (bh - o[a]) * inv[a];
-        const bool undefined = t0 != t0 || t1 != t1;
-        double a0 = fmin(t0, t1), a1 = fmax(t0, t1);
-        if (!undefined) lo = fmax(lo, a0), hi = fmin(hi, a1);
+        const double t0 = fma(bl, r.inv[a], -r.oi[a]), t1 = fma(bh, r.inv[a], -r.oi[a]);
+        lo = fmax(lo, fmin(t0, t1)), hi = fmin(hi, fmax(t0, t1));
     }
     return lo <= hi;
 }
 #define LDS_AS __attribute__((address_space(3)))
-// Candidate search for large trees (host side: build_candidate_tree). `bits` is this lane's
-// column of a [CAND_WORDS][BLOCK] bit array in LDS, one bit per tree node, all zero on entry and
-// on return. Phase 1 walks the spatial tree and marks every leaf whose tight box the ray's line
-// meets, together with the leaf's ancestors; phase 2 is the reference's walk over the marked
-// nodes (ascending index = pre-order), with the walk's own node code. Gives the walk's result.
+// Per-lane LDS state of the candidate search: a [CAND_WORDS][BLOCK] bit array, one bit per tree
+// node, all zero between queries, and a [CAND_STACK][BLOCK] node stack (columns of this lane).
+struct CandLds {
+    LDS_AS uint32_t* bits;
+    LDS_AS uint16_t* stack;
+};
+// Candidate search for large trees (host side: build_candidate_tree). Phase 1 walks the spatial
+// tree and marks every leaf whose tight box the ray's line meets, together with the leaf's
+// ancestors; phase 2 is the reference's walk over the marked nodes (ascending index =
+// pre-order), with the walk's own node code. Gives the walk's result.
 template <int FEAT>
-__device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, const Rng& g, HitD& out, LDS_AS uint32_t* bits) {
+__device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, const Rng& g, HitD& out, CandLds lds,
+                                       Stamps& st) {
     D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
+    LDS_AS uint32_t* bits = lds.bits;
+    const CandRay cr{{inv_d.x, inv_d.y, inv_d.z}, {ray.o.x * inv_d.x, ray.o.y * inv_d.y, ray.o.z * inv_d.z}, ray.time,
+                     ray.time < 0.0 ? 1 : 0};
+    REGION_BEGIN(search);
     {
-        int i = 0;
-        const int n = sv.n_cand_nodes;
-        while (i < n) {
-            const DCandNode* nd = sv.cand_nodes + i;
-            const int object = nd->object, skip = nd->skip;
-            if (!line_meets_box(nd, ray, inv_d)) {
-                i = skip;
-                continue;
+        int sp = 0;
+        int node = 0;
+        for (;;) {
+            const DCand4* nd = sv.cand_nodes + node;
+            const bool moving = nd->moving != 0;
+            STAMP_COUNT(st, 0);
+            int next = -1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int child = nd->child[k];
+                if (child == -1 || !line_meets_child(nd, k, moving, cr)) continue;
+                if (child >= 0) {
+                    // descend into the last child that was hit; the others wait on the stack
+                    // (the host has checked that CAND_STACK entries are enough for this tree)
+                    if (next >= 0) lds.stack[sp++ * BLOCK] = (uint16_t)next;
+                    next = child;
+                    continue;
+                }
+                // mark the leaf and its ancestors: one row of independent loads, LDS ORs that return nothing
+                const int4* row = reinterpret_cast<const int4*>(sv.cand_chain + (size_t)(-2 - child) * (size_t)sv.n_cand_depth);
+                for (int q = 0; q < sv.n_cand_depth / 4; ++q) {
+                    const int4 c = row[q];
+                    const int n4[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n4[e] >= 0)
+                            (void)__hip_atomic_fetch_or(bits + (n4[e] >> 5) * BLOCK, 1u << (n4[e] & 31), __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
-            for (int k = object; k >= 0; k = sv.cand_parent[k]) {
-                const uint32_t bit = 1u << (k & 31);
-                const uint32_t old = bits[(k >> 5) * BLOCK];
-                if (old & bit) break;  // this ancestor and all above it are marked already
-                bits[(k >> 5) * BLOCK] = old | bit;
+            if (next < 0) {
+                if (sp == 0) break;
+                next = lds.stack[--sp * BLOCK];
             }
-            i = i + 1;
+            node = next;
         }
     }
+    REGION_END(st, ST_CAND_SEARCH, search);
+    STAMP_COUNT(st, 3);
     LaneWalk w{(double)FLT_MAX, -1, 0, {0.0, 0.0, 0.0}, 0, 0};
+    // The marked nodes are known before any of them is visited, so the next node's record is
+    // requested while the current one is processed (the walk is bound by load latency).
     const int words = sv.n_cand_words;
+    int wd = 0;
+    uint32_t m = 0;
+    auto next_marked = [&]() -> int {  // ascending node indices; clears the words it reads
+        while (m == 0) {
+            if (wd >= words) return -1;
+            m = bits[wd * BLOCK];
+            if (m) bits[wd * BLOCK] = 0;
+            ++wd;
+        }
+        const int idx = (wd - 1) * 32 + __ffs((int)m) - 1;
+        m &= m - 1;
+        return idx;
+    };
     int resume = 0;  // nodes below this index lie in a subtree whose box test failed
-    for (int wd = 0; wd < words; ++wd) {
-        uint32_t m = bits[wd * BLOCK];
-        if (m == 0) continue;
-        bits[wd * BLOCK] = 0;
-        while (m) {
-            const int idx = wd * 32 + __ffs((int)m) - 1;
-            m &= m - 1;
-            if (idx < resume) continue;
-            const DNode nd = sv.nodes[idx];
+    int idx = next_marked();
+    DNode nd{};
+    if (idx >= 0) nd = sv.nodes[idx];
+    while (idx >= 0) {
+        const int idx_next = next_marked();
+        DNode nd_next{};
+        if (idx_next >= 0) nd_next = sv.nodes[idx_next];
+        if (idx >= resume) {
+            STAMP_COUNT(st, nd.object >= 0 ? 2 : 1);
             if (!lane_visit<FEAT>(sv, nd, ray, inv_d, g, w)) resume = nd.skip;
         }
+        idx = idx_next;
+        nd = nd_next;
     }
     out.t = w.closest;
     out.obj = w.best_obj;
@@ -920,8 +975,14 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
     return w.best_obj >= 0;
 }
 template <int FEAT>
-__device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng& g, HitD& out, LDS_AS uint32_t* bits = nullptr) {
-    if (sv.n_cand_nodes > 0 && bits) return nearest_hit_candidates<FEAT>(sv, ray, g, out, bits);
+__device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng& g, HitD& out, Stamps& st,
+                                 CandLds lds = CandLds{nullptr, nullptr}) {
+    // (a zero or non-finite direction component makes slab bounds undefined: those rays take the walk)
+    const double dmin = fmin(fabs(ray.d.x), fmin(fabs(ray.d.y), fabs(ray.d.z)));
+    const double dmax = fmax(fabs(ray.d.x), fmax(fabs(ray.d.y), fabs(ray.d.z)));
+    // (so do origins so far out that origin * inv loses the digits the boxes' safety margin covers)
+    const double omax = fmax(fabs(ray.o.x), fmax(fabs(ray.o.y), fabs(ray.o.z)));
+    if (sv.n_cand_nodes > 0 && lds.bits && dmin > 0.0 && dmax < INFINITY && omax < 1e6) return nearest_hit_candidates<FEAT>(sv, ray, g, out, lds, st);
     LaneWalk w{(double)FLT_MAX, -1, 0, {0.0, 0.0, 0.0}, 0, 0};
     D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
     int i = 0;
@@ -1666,7 +1727,7 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
 // path; with WAVE the traversal is wave-synchronous and every lane of the wave must call this.
 template <bool WAVE, int FEAT>
 __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, bool live, F3& radiance,
-                             uint32_t& rays, uint32_t& light_queries, Stamps& st, LDS_AS uint32_t* cand_bits) {
+                             uint32_t& rays, uint32_t& light_queries, Stamps& st, CandLds cand_bits) {
     radiance = {0.f, 0.f, 0.f};
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     bool hit;
@@ -1674,7 +1735,7 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
     if (WAVE) {
         hit = nearest_hit_wave<FEAT>(sv, ray, g, live, h, st);
     } else {
-        hit = live && nearest_hit_lane<FEAT>(sv, ray, g, h, cand_bits);
+        hit = live && nearest_hit_lane<FEAT>(sv, ray, g, h, st, cand_bits);
     }
     REGION_END(st, ST_TRAVERSE, trav);
     if (!live) return false;
@@ -1686,12 +1747,13 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
 }
 
 // ============================================================== kernels
-// This lane's column of the workgroup's candidate bit array (nearest_hit_candidates), cleared.
-__device__ __forceinline__ LDS_AS uint32_t* candidate_bits(const SceneView& sv) {
+// This lane's columns of the workgroup's candidate-search arrays (nearest_hit_candidates), bits cleared.
+__device__ __forceinline__ CandLds candidate_lds(const SceneView& sv) {
     __shared__ uint32_t cand_words[CAND_WORDS * BLOCK];
-    LDS_AS uint32_t* bits = (LDS_AS uint32_t*)cand_words + threadIdx.x;
-    for (int w = 0; w < sv.n_cand_words; ++w) bits[w * BLOCK] = 0;
-    return bits;
+    __shared__ uint16_t cand_stack[CAND_STACK * BLOCK];
+    CandLds lds{(LDS_AS uint32_t*)cand_words + threadIdx.x, (LDS_AS uint16_t*)cand_stack + threadIdx.x};
+    for (int w = 0; w < sv.n_cand_words; ++w) lds.bits[w * BLOCK] = 0;
+    return lds;
 }
 // Waves per SIMD the segment kernel is compiled for (512 / waves registers per lane). Measured:
 // three waves hide the scene-record and pool latencies best as long as the kernel fits 168
@@ -1739,8 +1801,8 @@ __global__ void __launch_bounds__(BLOCK, seg_waves(WAVE, FEAT)) k_segments(Scene
     chunk_end = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(chunk_end >> 32)) << 32) |
                 __builtin_amdgcn_readfirstlane((uint32_t)chunk_end);
     bool dry = false;  // the global counter has run past the end of the work
-    LDS_AS uint32_t* cand_bits = nullptr;
-    if constexpr (!WAVE) cand_bits = candidate_bits(sv);
+    CandLds cand_bits{nullptr, nullptr};
+    if constexpr (!WAVE) cand_bits = candidate_lds(sv);
     Stamps st{};
     REGION_BEGIN(total);
     for (uint32_t step = 0; step < rp.steps; ++step) {
@@ -1823,6 +1885,8 @@ __global__ void __launch_bounds__(BLOCK, seg_waves(WAVE, FEAT)) k_segments(Scene
 #ifdef MRT_STAMPS
     for (int i = 0; i < ST_COUNT; ++i)
         if (st.acc[i]) atomicAdd(&ctr->stamps[i], st.acc[i]), atomicAdd(&ctr->stamp_lanes[i], st.lanes[i]);
+    for (int i = 0; i < 4; ++i)
+        if (st.count[i]) atomicAdd(&ctr->stamp_counts[i], (unsigned long long)st.count[i]);
 #endif
     if (in_range) {
         pool.seg[slot] = seg;
@@ -1905,7 +1969,7 @@ __global__ void __launch_bounds__(BLOCK) k_single_bounce(SceneView sv, RenderPar
     uint32_t rays = live ? 1u : 0u;
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     Rng g0(key, 0);
-    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g0, live, h, st) : (live && nearest_hit_lane<FEAT>(sv, ray, g0, h));
+    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g0, live, h, st) : (live && nearest_hit_lane<FEAT>(sv, ray, g0, h, st));
     F3 color{0.f, 0.f, 0.f};
     if constexpr (MODE == MRT_SHADER_DIFFUSE) {
         if (live) color = diffuse_stage<FEAT>(sv, ray, h, hit);
@@ -1928,7 +1992,7 @@ __global__ void __launch_bounds__(BLOCK) k_single_bounce(SceneView sv, RenderPar
             if (hit) object_generate<LF>(lights + i, pos_w, h.t, gi, rng_f64(gi, MRT_DIM_LIGHT_A), rng_f64(gi, MRT_DIM_LIGHT_B), ai);
             HitD h2{0.0, -1, 0, {0.0, 0.0, 0.0}};
             bool hit2 = WAVE ? nearest_hit_wave<FEAT>(sv, ai.to_area, gi, hit, h2, st)
-                             : (hit && nearest_hit_lane<FEAT>(sv, ai.to_area, gi, h2));
+                             : (hit && nearest_hit_lane<FEAT>(sv, ai.to_area, gi, h2, st));
             if (hit) rays++;
             if (hit && hit2) {
                 const DObjRec* ob2 = sv.objects + h2.obj;
@@ -2006,9 +2070,9 @@ __global__ void __launch_bounds__(BLOCK) k_trace_rays(SceneView sv, const double
     Rng g{path_key(seed, (uint64_t)i, 0), 0};
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     Stamps st{};
-    LDS_AS uint32_t* cand_bits = nullptr;
-    if constexpr (!WAVE) cand_bits = candidate_bits(sv);
-    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g, live, h, st) : (live && nearest_hit_lane<FEAT>(sv, ray, g, h, cand_bits));
+    CandLds cand_bits{nullptr, nullptr};
+    if constexpr (!WAVE) cand_bits = candidate_lds(sv);
+    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g, live, h, st) : (live && nearest_hit_lane<FEAT>(sv, ray, g, h, st, cand_bits));
     if (!live) return;
     D3 n_w{0, 0, 0}, p_w{0, 0, 0};
     if (hit) {
@@ -2176,7 +2240,7 @@ int upload_scene(mrt_scene* sc) {
     UP(f.nodes, nodes)
     if ((rc = m.upload(f.node_recs, &sc->dev_node_recs)) != MRT_OK) return rc;
     if ((rc = m.upload(f.leaf_recs, &sc->dev_leaf_recs)) != MRT_OK) return rc;
-    UP(f.cand_nodes, cand_nodes) UP(f.cand_parent, cand_parent)
+    UP(f.cand_nodes, cand_nodes) UP(f.cand_chain, cand_chain)
     UP(f.obj_recs, objects) UP(f.light_recs, lights)
     UP(f.textures, textures) UP(f.images, images) UP(f.image_pool, image_pool) UP(f.perlins, perlins)
     UP(f.octrees, octrees) UP(f.oct_nodes, oct_nodes) UP(f.oct_voxels, oct_voxels)
@@ -2184,6 +2248,7 @@ int upload_scene(mrt_scene* sc) {
     v.n_nodes = (int32_t)f.node_object.size();
     v.n_cand_nodes = (int32_t)f.cand_nodes.size();
     v.n_cand_words = f.cand_nodes.empty() ? 0 : (int32_t)((f.node_object.size() + 31) / 32);
+    v.n_cand_depth = f.cand_depth;
     v.n_objects = (int32_t)f.objects.size();
     v.n_lights = (int32_t)f.lights.size();
     v.cam = f.camera;
@@ -2357,7 +2422,11 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
 #ifdef MRT_STAMPS
     {
         static const char* names[ST_COUNT] = {"regen", "traverse(all)", "  leaf:solid", "surface+texture", "lambert:generate",
-                                              "lambert:light value", "shade(all)", "accumulate", "total", "  leaf:medium", "  regen:claim", "  gen:cosine", "  gen:light", "  gen:sky", "isotropic scatter"};
+                                              "lambert:light value", "shade(all)", "accumulate", "total", "  leaf:medium", "  regen:claim", "  gen:cosine", "  gen:light", "  gen:sky", "isotropic scatter", "  candidate search"};
+        std::fprintf(stderr, "[stamps] candidate search per query: %.1f spatial nodes, %.1f marked inner nodes, %.1f marked leaves (%llu queries)\n",
+                     (double)host.stamp_counts[0] / (double)std::max(1ull, host.stamp_counts[3]),
+                     (double)host.stamp_counts[1] / (double)std::max(1ull, host.stamp_counts[3]),
+                     (double)host.stamp_counts[2] / (double)std::max(1ull, host.stamp_counts[3]), host.stamp_counts[3]);
         std::fprintf(stderr, "[stamps] wave-cycles per region (share of total, active lanes of 64)\n");
         for (int i = 0; i < ST_COUNT; ++i)
             std::fprintf(stderr, "[stamps] %-22s %14llu  %5.1f%%  lanes %4.1f\n", names[i], host.stamps[i],

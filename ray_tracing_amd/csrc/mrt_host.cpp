@@ -321,12 +321,16 @@ bool tight_box(const FlatScene& s, const DObject& o, CandItem* it) {
         if (!std::isfinite(b.mn[i]) || !std::isfinite(b.mx[i]) || !std::isfinite(it->v[i])) return false;
         double m = 1e-9 * (1.0 + std::max(std::fabs(b.mn[i]), std::fabs(b.mx[i])));  // margin against rounding
         b.mn[i] -= m, b.mx[i] += m;
-        const double tau = 2.0;  // bounce distances of a few units are the common ray times
-        it->sah.mn[i] = b.mn[i] + std::min(0.0, tau * it->v[i]);
-        it->sah.mx[i] = b.mx[i] + std::max(0.0, tau * it->v[i]);
+        it->sah.mn[i] = b.mn[i], it->sah.mx[i] = b.mx[i];
     }
     return true;
 }
+// Binary build node (pre-order, skip links); collapsed into four-wide nodes afterwards.
+struct Cand2 {
+    double lo[3], hi[3], vlo[3], vhi[3];
+    int32_t object, skip;
+    Box sah;
+};
 double half_area(const Box& b) {
     double d[3] = {b.mx[0] - b.mn[0], b.mx[1] - b.mn[1], b.mx[2] - b.mn[2]};
     return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
@@ -336,11 +340,13 @@ void grow(Box* a, const Box& b) {
 }
 const Box kEmptyBox{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
 // Surface-area-heuristic split by full sweeps over the three centroid orders; emits pre-order nodes.
-void build_candidate_nodes(std::vector<CandItem>& items, size_t lo, size_t hi, std::vector<DCandNode>* out) {
+void build_candidate_nodes(std::vector<CandItem>& items, size_t lo, size_t hi, std::vector<Cand2>* out) {
     const size_t me = out->size();
-    out->push_back(DCandNode{});
-    DCandNode nd{};
+    out->push_back(Cand2{});
+    Cand2 nd{};
     nd.object = -1;
+    nd.sah = kEmptyBox;
+    for (size_t i = lo; i < hi; ++i) grow(&nd.sah, items[i].sah);
     for (int a = 0; a < 3; ++a) nd.lo[a] = INFINITY, nd.hi[a] = -INFINITY, nd.vlo[a] = INFINITY, nd.vhi[a] = -INFINITY;
     for (size_t i = lo; i < hi; ++i)
         for (int a = 0; a < 3; ++a) {
@@ -348,7 +354,6 @@ void build_candidate_nodes(std::vector<CandItem>& items, size_t lo, size_t hi, s
             nd.vlo[a] = std::min(nd.vlo[a], items[i].v[a]), nd.vhi[a] = std::max(nd.vhi[a], items[i].v[a]);
         }
     for (int a = 0; a < 3; ++a) {
-        if (nd.vlo[a] != 0.0 || nd.vhi[a] != 0.0) nd.moving = 1;
         // widen the velocity interval a little: tau * v is rounded differently from the shape's own centre formula
         nd.vlo[a] -= 1e-9 * std::fabs(nd.vlo[a]), nd.vhi[a] += 1e-9 * std::fabs(nd.vhi[a]);
     }
@@ -386,9 +391,69 @@ void build_candidate_nodes(std::vector<CandItem>& items, size_t lo, size_t hi, s
     nd.skip = (int32_t)out->size();
     (*out)[me] = nd;
 }
+// Collapses the binary tree below node `i` into a four-wide node; returns its index and the stack
+// depth the device traversal needs below it (it descends into the last child that was hit and keeps
+// the others on the stack).
+int collapse(const std::vector<Cand2>& b2, int i, std::vector<DCand4>* out, int* need) {
+    std::vector<int> kids;
+    if (b2[(size_t)i].object >= 0) {
+        kids.push_back(i);  // a tree of one leaf
+    } else {
+        kids = {i + 1, b2[(size_t)i + 1].skip};
+        while (kids.size() < 4) {
+            int pick = -1;
+            double area = -1.0;
+            for (size_t k = 0; k < kids.size(); ++k)
+                if (b2[(size_t)kids[k]].object < 0 && half_area(b2[(size_t)kids[k]].sah) > area)
+                    area = half_area(b2[(size_t)kids[k]].sah), pick = (int)k;
+            if (pick < 0) break;
+            int c = kids[(size_t)pick];
+            kids[(size_t)pick] = c + 1;
+            kids.push_back(b2[(size_t)c + 1].skip);
+        }
+    }
+    const int me = (int)out->size();
+    out->push_back(DCand4{});
+    struct Kid {
+        int b2, index, need;
+    };
+    std::vector<Kid> inner, leaves;
+    for (int c : kids) {
+        if (b2[(size_t)c].object >= 0) {
+            leaves.push_back({c, -2 - b2[(size_t)c].object, 0});
+        } else {
+            int n = 0;
+            int idx = collapse(b2, c, out, &n);
+            inner.push_back({c, idx, n});
+        }
+    }
+    // the child with the deepest stack demand first: it is entered with the fewest siblings waiting
+    std::stable_sort(inner.begin(), inner.end(), [](const Kid& a, const Kid& b) { return a.need > b.need; });
+    *need = 0;
+    for (size_t j = 0; j < inner.size(); ++j) *need = std::max(*need, (int)j + inner[j].need);
+    DCand4 nd{};
+    std::vector<Kid> all(inner);
+    all.insert(all.end(), leaves.begin(), leaves.end());
+    for (int k = 0; k < 4; ++k) {
+        nd.child[k] = -1;
+        for (int a = 0; a < 3; ++a) nd.lo[a][k] = INFINITY, nd.hi[a][k] = -INFINITY;
+        if ((size_t)k >= all.size()) continue;
+        const Cand2& c = b2[(size_t)all[(size_t)k].b2];
+        nd.child[k] = all[(size_t)k].index;
+        for (int a = 0; a < 3; ++a) {
+            nd.lo[a][k] = c.lo[a], nd.hi[a][k] = c.hi[a];
+            nd.v_for_lo[0][a][k] = c.vlo[a], nd.v_for_lo[1][a][k] = c.vhi[a];
+            nd.v_for_hi[0][a][k] = c.vhi[a], nd.v_for_hi[1][a][k] = c.vlo[a];
+            if (c.vlo[a] != 0.0 || c.vhi[a] != 0.0) nd.moving = 1;
+        }
+    }
+    (*out)[(size_t)me] = nd;
+    return me;
+}
 void build_candidate_tree(FlatScene* s) {
     if (s->nodes.size() > (size_t)CAND_MAX_NODES) return;
     std::vector<CandItem> items;
+    std::vector<int32_t> leaf_order;  // row -> index of the leaf in `nodes`
     for (size_t i = 0; i < s->nodes.size(); ++i) {
         const DNode& nd = s->nodes[i];
         if (nd.object < 0) continue;
@@ -396,18 +461,45 @@ void build_candidate_tree(FlatScene* s) {
         if ((nd.flags & NODE_TWICE) || shape_is_stochastic(*s, ob.shape)) return;
         CandItem it;
         if (!tight_box(*s, ob, &it)) return;
-        it.node = (int32_t)i;
+        it.node = (int32_t)leaf_order.size();  // row of the ancestor table
+        leaf_order.push_back((int32_t)i);
         items.push_back(it);
     }
     if (items.empty()) return;
-    build_candidate_nodes(items, 0, items.size(), &s->cand_nodes);
-    // parents in the pre-order node array: a node's subtree ends at its skip link
-    s->cand_parent.assign(s->nodes.size(), -1);
-    std::vector<int32_t> open;
+    // group by where the leaves are for ray times of a few units (bounce distances); the bounds
+    // themselves hold for every ray time
+    for (CandItem& it : items)
+        for (int i = 0; i < 3; ++i) {
+            it.sah.mn[i] = it.a.mn[i] + std::min(0.0, 2.0 * it.v[i]);
+            it.sah.mx[i] = it.a.mx[i] + std::max(0.0, 2.0 * it.v[i]);
+        }
+    std::vector<Cand2> b2;
+    build_candidate_nodes(items, 0, items.size(), &b2);
+    int need = 0;
+    collapse(b2, 0, &s->cand_nodes, &need);
+    if (need > CAND_STACK || s->cand_nodes.size() > 65535) {
+        s->cand_nodes.clear();
+        return;
+    }
+    // ancestor rows: parents in the pre-order node array (a node's subtree ends at its skip link)
+    std::vector<int32_t> parent(s->nodes.size(), -1), open;
     for (size_t i = 0; i < s->nodes.size(); ++i) {
         while (!open.empty() && s->nodes[(size_t)open.back()].skip <= (int32_t)i) open.pop_back();
-        s->cand_parent[i] = open.empty() ? -1 : open.back();
+        parent[i] = open.empty() ? -1 : open.back();
         if (s->nodes[i].object < 0) open.push_back((int32_t)i);
+    }
+    int depth = 0;
+    for (int32_t leaf : leaf_order) {
+        int d = 0;
+        for (int32_t n = leaf; n >= 0; n = parent[(size_t)n]) ++d;
+        depth = std::max(depth, d);
+    }
+    depth = (depth + 3) / 4 * 4;  // rows are read four entries at a time
+    s->cand_depth = depth;
+    s->cand_chain.assign(leaf_order.size() * (size_t)depth, -1);
+    for (size_t row = 0; row < leaf_order.size(); ++row) {
+        size_t k = row * (size_t)depth;
+        for (int32_t n = leaf_order[row]; n >= 0; n = parent[(size_t)n]) s->cand_chain[k++] = n;
     }
 }
 

@@ -80,9 +80,11 @@ enum : int32_t {
     NODE_TWICE = 2         // span-1 leaf pair folded into one node; evaluate the object twice (bvh.rs:224-232)
 };
 
-// Largest tree (nodes) the candidate search handles: one bit per node and lane in LDS.
-constexpr int CAND_WORDS = 48;
+// Candidate search: largest tree (nodes) it handles -- one bit per node and lane in LDS -- and the
+// depth of the per-lane node stack of its spatial tree, also in LDS.
+constexpr int CAND_WORDS = 32;
 constexpr int CAND_MAX_NODES = CAND_WORDS * 32;
+constexpr int CAND_STACK = 32;
 
 // Device BVH node of the per-lane walk: one 64-byte line per node.
 struct DNode {
@@ -94,20 +96,21 @@ struct DNode {
 };
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
 
-// Node of the spatial tree of the candidate search. Its box at ray time tau is
-// [lo + min(tau * vlo, tau * vhi), hi + max(tau * vlo, tau * vhi)]: a MovingSphere's centre is
-// linear in the ray's time (sphere.rs:139-142), and scattered rays carry arbitrary times
-// (ray_tracer.rs:242,261 set time = hit t), so the bound has to hold for every tau.
-struct DCandNode {
-    double lo[3], hi[3];
-    int32_t object;  // leaf: index of the leaf it stands for in FlatScene::nodes; inner: -1
-    int32_t skip;
-    int32_t moving;  // 0: vlo = vhi = 0
-    int32_t pad;
-    double vlo[3], vhi[3];
-    double pad2[2];
+// Node of the spatial tree of the candidate search: four children with their boxes, one record
+// per visit. A child's box at ray time tau is [lo + min(tau * vlo, tau * vhi), hi + max(tau * vlo,
+// tau * vhi)]: a MovingSphere's centre is linear in the ray's time (sphere.rs:139-142), and
+// scattered rays carry arbitrary times (ray_tracer.rs:242,261 set time = hit t), so the bound has
+// to hold for every tau. The velocity bounds are stored twice, indexed by the sign of tau, which
+// turns the min/max of the interval product into one fma per corner.
+struct DCand4 {
+    int32_t child[4];  // >= 0: node index; -1: none; <= -2: leaf, row (-2 - child) of FlatScene::cand_chain
+    int32_t moving;    // 0: every velocity bound is 0
+    int32_t pad[3];
+    double lo[3][4], hi[3][4];
+    double v_for_lo[2][3][4];  // [tau < 0]: velocity bound that gives the lower corner
+    double v_for_hi[2][3][4];  // [tau < 0]: velocity bound that gives the upper corner
 };
-static_assert(sizeof(DCandNode) == 128, "DCandNode must be 128 bytes");
+static_assert(sizeof(DCand4) == 608, "DCand4 layout");
 
 // One self-contained record per device BVH node for the wave-synchronous walk: everything the
 // box test and the leaf's intersection test need, so a node costs one batch of scalar loads
@@ -183,10 +186,11 @@ struct FlatScene {
     std::vector<DNodeRec> leaf_recs;
     std::vector<DObjRec> obj_recs, light_recs;
     // Candidate search for large trees (see build_candidate_tree): a spatial tree over tight boxes of
-    // the leaves of `nodes`, in pre-order with skip links, and the parent of every node of `nodes`
-    // (-1 for the root). Empty when the scene does not qualify.
-    std::vector<DCandNode> cand_nodes;
-    std::vector<int32_t> cand_parent;
+    // the leaves of `nodes`, and per leaf one row of cand_depth entries of cand_chain holding the
+    // leaf's index in `nodes` and those of its ancestors (-1 padded). Empty when the scene does not qualify.
+    std::vector<DCand4> cand_nodes;
+    std::vector<int32_t> cand_chain;
+    int32_t cand_depth = 0;
     bool has_medium = false;
 };
 
