@@ -326,6 +326,21 @@ int mrt_render_accumulate(mrt_scene* scene, float* accum_rgb, uint32_t width, ui
                           uint32_t x0, uint32_t strip_w, uint32_t spp, uint64_t seed,
                           uint64_t first_sample_index, mrt_stats* stats);
 
+/* Same samples, split over several scene handles -- normally one per GPU,
+ * created from the same description -- for a single-process host such as the
+ * reference's (ray_tracer.rs:479-535 drives all its workers from one process).
+ * Handle i renders the i-th share of the sample range
+ * [first_sample_index, first_sample_index + spp) on its own device, concurrently
+ * with the others; the shares are then added into `accum_rgb` (HOST memory) in
+ * handle order, so the result is the one-handle result up to the order of the
+ * f32 additions. `stats`: sums of the counters, the longest kernel time, the
+ * wall time of the call. Multi-process hosts split the samples the same way and
+ * all-reduce the buffers instead (one rank per GPU). */
+int mrt_render_accumulate_multi(mrt_scene* const* scenes, uint32_t n_scenes, float* accum_rgb,
+                                uint32_t width, uint32_t height, uint32_t x0, uint32_t strip_w,
+                                uint32_t spp, uint64_t seed, uint64_t first_sample_index,
+                                mrt_stats* stats);
+
 /* Same, with `accum_rgb_device` resident on the scene's device (e.g. a torch
  * tensor's data pointer). `stream` is a hipStream_t (NULL = default stream);
  * the call returns after the work has completed on that stream. */

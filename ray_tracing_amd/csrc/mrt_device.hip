@@ -17,11 +17,13 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -2642,6 +2644,63 @@ int mrt_render_accumulate(mrt_scene* scene, float* accum_rgb, uint32_t width, ui
     rc = render_device(scene, dacc, width, height, x0, strip_w, spp, seed, first_sample_index, nullptr, stats);
     if (rc != MRT_OK) return rc;
     HIP_TRY(hipMemcpy(accum_rgb, dacc, bytes, hipMemcpyDeviceToHost));
+    return MRT_OK;
+}
+
+int mrt_render_accumulate_multi(mrt_scene* const* scenes, uint32_t n_scenes, float* accum_rgb, uint32_t width,
+                                uint32_t height, uint32_t x0, uint32_t strip_w, uint32_t spp, uint64_t seed,
+                                uint64_t first_sample_index, mrt_stats* stats) {
+    if (!scenes || n_scenes == 0) return set_error(MRT_ERR_INVALID_ARGUMENT, "no scene handles");
+    for (uint32_t i = 0; i < n_scenes; ++i)
+        if (!scenes[i] || scenes[i]->device < 0) return set_error(MRT_ERR_INVALID_ARGUMENT, "scene has no device image");
+    if (!accum_rgb) return set_error(MRT_ERR_INVALID_ARGUMENT, "accumulation buffer is NULL");
+    if (width < 2 || height < 2 || (uint64_t)width * height > 0xFFFFFFFFull / 3)
+        return set_error(MRT_ERR_INVALID_ARGUMENT, "bad image size");
+    if (x0 >= width || strip_w == 0 || strip_w > width - x0) return set_error(MRT_ERR_INVALID_ARGUMENT, "strip outside the image");
+    const auto t_begin = std::chrono::steady_clock::now();
+    const size_t n_float = 3 * (size_t)width * height;
+    struct Share {
+        std::vector<float> image;
+        mrt_stats stats{};
+        int rc = MRT_OK;
+        std::string message;
+        uint32_t spp = 0;
+        uint64_t first = 0;
+    };
+    std::vector<Share> shares(n_scenes);
+    uint64_t next = first_sample_index;
+    for (uint32_t i = 0; i < n_scenes; ++i) {
+        shares[i].spp = spp / n_scenes + (i < spp % n_scenes ? 1u : 0u);
+        shares[i].first = next;
+        next += shares[i].spp;
+    }
+    std::vector<std::thread> workers;
+    for (uint32_t i = 0; i < n_scenes; ++i) {
+        if (shares[i].spp == 0) continue;
+        workers.emplace_back([&, i] {
+            Share& s = shares[i];
+            s.image.assign(n_float, 0.0f);
+            s.rc = mrt_render_accumulate(scenes[i], s.image.data(), width, height, x0, strip_w, s.spp, seed, s.first, &s.stats);
+            if (s.rc != MRT_OK) s.message = g_last_error;  // the worker thread's message
+        });
+    }
+    for (std::thread& w : workers) w.join();
+    for (const Share& s : shares)
+        if (s.rc != MRT_OK) return set_error(s.rc, s.message);
+    mrt_stats total{};
+    for (const Share& s : shares) {
+        if (s.spp == 0) continue;
+        for (uint32_t y = 0; y < height; ++y) {
+            const size_t row = ((size_t)y * width + x0) * 3;
+            for (size_t k = row; k < row + (size_t)strip_w * 3; ++k) accum_rgb[k] += s.image[k];
+        }
+        total.paths += s.stats.paths, total.rays += s.stats.rays, total.light_queries += s.stats.light_queries;
+        total.launches += s.stats.launches;
+        total.kernel_ms = std::max(total.kernel_ms, s.stats.kernel_ms);
+        total.segment_kernel_avg_ms = std::max(total.segment_kernel_avg_ms, s.stats.segment_kernel_avg_ms);
+    }
+    total.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (stats) *stats = total;
     return MRT_OK;
 }
 

@@ -183,6 +183,20 @@ class RayTracer:
         self.last_stats = _stats(st)
         return self.last_stats
 
+    def trace_part_multi(self, others: list, part: ParallelImagePart, num_samples: int,
+                         first_sample: Optional[int] = None) -> RenderStats:
+        """trace_part with the samples split over this tracer's scene handle and those of `others`
+        (normally one RayTracer per GPU built from the same WorldInfo), in one process."""
+        img = part.image
+        fs = self._next_sample if first_sample is None else first_sample
+        handles = [self.world.handle] + [o.world.handle for o in others]
+        arr = (C.c_void_p * len(handles))(*handles)
+        st = F.Stats()
+        F.check(self._lib.mrt_render_accumulate_multi(arr, len(handles), img.buffer.ctypes.data, img.width, img.height,
+                                                      part.offset_x, part.width, num_samples, self.seed, fs, C.byref(st)))
+        self.last_stats = _stats(st)
+        return self.last_stats
+
     def trace_image(self, rgb_img: ParallelImage) -> RenderStats:  # ray_tracer.rs:413-418
         st = self.trace_part(rgb_img.split(1)[0], 1)
         self._next_sample += 1

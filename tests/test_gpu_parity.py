@@ -293,3 +293,31 @@ def test_full_size_properties_voxel_city_4k(worlds):
     # the sky above the skyline is the SunSky gradient: no geometry, exactly one ray per path there
     top = a[H - 40:, :400, :] / 2
     assert top.min() > 0.0 and top.max() < 0.06
+
+
+def test_samples_split_over_scene_handles_in_one_process():
+    """mrt_render_accumulate_multi: three handles (here on one GPU) render disjoint sample shares concurrently;
+    the sum is the one-handle image up to the order of the f32 additions. 7 samples over 3 handles: 3 + 2 + 2."""
+    info = scenarios.cornell_smoke()
+    rts = [RayTracer(info, device=0, seed=21) for _ in range(3)]
+    W, H, spp = 83, 47, 7
+    ref, rst = gpu_render(rts[0], W, H, spp, first=5)
+    img = ParallelImage(np.full((H, W, 3), 0.5, dtype=np.float32))
+    part = img.split(1)[0]
+    part.offset_x, part.width = 3, 70
+    st = rts[0].trace_part_multi(rts[1:], part, spp, first_sample=5)
+    assert st.paths == 70 * H * spp and st.launches >= 3
+    want = np.full((H, W, 3), 0.5, dtype=np.float32)
+    strip_ref, _ = gpu_render(rts[0], W, H, spp, first=5, x0=3, strip_w=70)
+    want[:, 3:73] += strip_ref[:, 3:73]
+    np.testing.assert_allclose(img.buffer, want, rtol=1e-5, atol=1e-6)
+    assert (img.buffer[:, :3] == 0.5).all() and (img.buffer[:, 73:] == 0.5).all()
+    # more handles than samples: the idle ones do nothing; the same handle twice is allowed (calls serialise)
+    img2 = ParallelImage.new_black(W, H)
+    st2 = rts[0].trace_part_multi([rts[0], rts[1], rts[2]], img2.split(1)[0], 2, first_sample=5)
+    two, _ = gpu_render(rts[0], W, H, 2, first=5)
+    assert st2.paths == W * H * 2
+    np.testing.assert_allclose(img2.buffer, two, rtol=1e-5, atol=1e-6)
+    from ray_tracing_amd import _ffi as F
+    lib = F.load()
+    assert lib.mrt_render_accumulate_multi(None, 0, img2.buffer.ctypes.data, W, H, 0, W, 1, 0, 0, None) == F.MRT_ERR_INVALID_ARGUMENT
