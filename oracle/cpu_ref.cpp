@@ -1677,4 +1677,11 @@ int oracle_to_image(const float* accum_rgb, uint32_t width, uint32_t height, uin
     return MRT_OK;
 }
 
+// Aabb::approx_eq (bvh.rs:56-70): the six absolute differences sum to less than 0.001.
+int oracle_aabb_approx_eq(const double* a_min, const double* a_max, const double* b_min, const double* b_max) {
+    double total = 0.0;
+    for (int i = 0; i < 3; ++i) total += std::fabs(a_min[i] - b_min[i]) + std::fabs(a_max[i] - b_max[i]);
+    return total < 0.001 ? 1 : 0;
+}
+
 }  // extern "C"

@@ -190,3 +190,13 @@ def test_perlin_texture_against_numpy_restatement():
     assert want.std() > 0.05                       # it is a pattern, not a constant
     np.testing.assert_allclose(img[..., 0], want, rtol=1e-5, atol=1e-6)
     assert (img[..., 0] == img[..., 1]).all() and (img[..., 1] == img[..., 2]).all()
+
+
+def test_aabb_approx_eq(oracle):
+    """bvh.rs:298-312: the reference's only test of its box type."""
+    import ctypes as C
+    lib = oracle
+    v = lambda *x: (C.c_double * 3)(*x)
+    eq = lambda a, b: lib.oracle_aabb_approx_eq(a[0], a[1], b[0], b[1])
+    unit, zero = (v(0, 0, 0), v(1, 1, 1)), (v(0, 0, 0), v(0, 0, 0))
+    assert eq(unit, unit) == 1 and eq(unit, zero) == 0 and eq(zero, zero) == 1 and eq(zero, unit) == 0
