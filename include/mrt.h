@@ -397,8 +397,8 @@ enum mrt_shader { MRT_SHADER_RAYTRACING = 0, MRT_SHADER_DIFFUSE = 1, MRT_SHADER_
  *                            4 candidate search (a spatial tree finds the leaves a
  *                            ray can meet; the tree walk then runs over those
  *                            leaves and their ancestors only; auto picks it for
- *                            trees of more than 64 nodes; scenes with media, volume
- *                            voxels or more than 1536 tree nodes fall back to 1)
+ *                            trees of more than 64 nodes; scenes with media, octrees
+ *                            or more than 1024 tree nodes fall back to 1)
  *   "trace_zero_throughput"  1: keep walking paths whose throughput is exactly
  *                            zero, as the reference does (same image, counters
  *                            match the reference's)

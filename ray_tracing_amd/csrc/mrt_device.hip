@@ -440,6 +440,45 @@ __device__ __forceinline__ DOctNode oct_chunk(const DOctNode* nodes, uint32_t ro
     }
     return n;
 }
+// The same lookup for a walk that moves from cell to neighbouring cell: the parents on the path to
+// the previous cell are remembered per lane (their child links, by size exponent, in LDS), and the
+// descent restarts at the smallest parent that also contains the new cell, which is one or two
+// levels up for most steps instead of the whole depth from the root. Same node as oct_chunk.
+constexpr int OCT_ANC_LEVELS = 16;
+struct OctCursor {
+    uint32_t* anc;      // this lane's column of a [OCT_ANC_LEVELS][BLOCK] array
+    int32_t x, y, z;    // cell of the previous lookup
+    uint32_t leaf_exp;  // size exponent of the node it returned
+    bool valid;
+};
+__device__ __forceinline__ DOctNode oct_chunk_near(const DOctNode* nodes, uint32_t root, uint32_t world_log2, OctCursor& c,
+                                                   int32_t x, int32_t y, int32_t z) {
+    DOctNode n;
+    bool from_root = true;
+    if (c.valid) {
+        const uint32_t diff = (uint32_t)((x ^ c.x) | (y ^ c.y) | (z ^ c.z));
+        const uint32_t h = 32u - (uint32_t)__clz((int)diff);  // cells agree above bit h - 1 (__clz(0) = 32)
+        const uint32_t s = h > c.leaf_exp + 1 ? h : c.leaf_exp + 1;  // smallest remembered parent that holds both
+        if (s <= world_log2) {
+            const uint32_t cs = s - 1;
+            const uint32_t ci = ((((uint32_t)x >> cs) & 1u) << 2) | ((((uint32_t)y >> cs) & 1u) << 1) | (((uint32_t)z >> cs) & 1u);
+            n = nodes[c.anc[s * BLOCK] + ci];
+            from_root = false;
+        }
+    }
+    if (from_root) n = nodes[root];
+    while ((n.kind_size & 0xFF) == MRT_OCT_PARENT) {
+        const uint32_t s = n.kind_size >> 8;
+        c.anc[s * BLOCK] = (uint32_t)n.link;
+        const uint32_t cs = s - 1;
+        const uint32_t ci = ((((uint32_t)x >> cs) & 1u) << 2) | ((((uint32_t)y >> cs) & 1u) << 1) | (((uint32_t)z >> cs) & 1u);
+        n = nodes[(uint32_t)n.link + ci];
+    }
+    c.x = x, c.y = y, c.z = z;
+    c.leaf_exp = n.kind_size >> 8;
+    c.valid = world_log2 < (uint32_t)OCT_ANC_LEVELS;
+    return n;
+}
 __device__ __forceinline__ int32_t f64_as_i32(double v) {  // Rust `as i32`: toward zero, saturating, NaN -> 0
     if (v != v) return 0;
     if (v >= 2147483647.0) return 2147483647;
@@ -525,7 +564,9 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
         return x >= 0 && x < ws && y >= 0 && y < ws && z >= 0 && z < ws;
     };
     if (!in_range(bx, by, bz)) return false;  // get_chunk(..).expect("out of range")
-    DOctNode chunk = oct_chunk(nodes, oc.root, bx, by, bz);
+    __shared__ uint32_t oct_anc[OCT_ANC_LEVELS * BLOCK];
+    OctCursor cursor{oct_anc + threadIdx.x, 0, 0, 0, 0, false};
+    DOctNode chunk = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, bx, by, bz);
     uint32_t csz = chunk.kind_size >> 8;
     bx = floor_size(bx, csz), by = floor_size(by, csz), bz = floor_size(bz, csz);
     D3 cur = origin;
@@ -557,7 +598,7 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
                 bx += step * (__builtin_signbit(d.x) ? -1 : 1);
                 cur.x += tx * d.x;
                 if (!in_range(bx, cy, cz)) return false;
-                node = oct_chunk(nodes, oc.root, bx, cy, cz);
+                node = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, bx, cy, cz);
                 uint32_t ncs = node.kind_size >> 8;
                 by = floor_size(cy, ncs), bz = floor_size(cz, ncs);
                 normal_code = 0;
@@ -565,7 +606,7 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
                 if (!in_range(bx - 1, by, bz)) return false;
                 cur.x += tx * d.x;
                 if (!in_range(bx - 1, cy, cz)) return false;  // get_chunk_size panics out of range
-                node = oct_chunk(nodes, oc.root, bx - 1, cy, cz);
+                node = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, bx - 1, cy, cz);
                 uint32_t ncs = node.kind_size >> 8;
                 by = floor_size(cy, ncs), bz = floor_size(cz, ncs);
                 bx -= 1 << ncs;
@@ -579,7 +620,7 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
                 by += step * (__builtin_signbit(d.y) ? -1 : 1);
                 cur.y += ty * d.y;
                 if (!in_range(cx, by, cz)) return false;
-                node = oct_chunk(nodes, oc.root, cx, by, cz);
+                node = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, cx, by, cz);
                 uint32_t ncs = node.kind_size >> 8;
                 bx = floor_size(cx, ncs), bz = floor_size(cz, ncs);
                 normal_code = 2;
@@ -587,7 +628,7 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
                 if (!in_range(bx, by - 1, bz)) return false;
                 cur.y += ty * d.y;
                 if (!in_range(cx, by - 1, cz)) return false;
-                node = oct_chunk(nodes, oc.root, cx, by - 1, cz);
+                node = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, cx, by - 1, cz);
                 uint32_t ncs = node.kind_size >> 8;
                 bx = floor_size(cx, ncs), bz = floor_size(cz, ncs);
                 by -= 1 << ncs;
@@ -601,7 +642,7 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
                 bz += step * (__builtin_signbit(d.z) ? -1 : 1);
                 cur.z += tz * d.z;
                 if (!in_range(cx, cy, bz)) return false;
-                node = oct_chunk(nodes, oc.root, cx, cy, bz);
+                node = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, cx, cy, bz);
                 uint32_t ncs = node.kind_size >> 8;
                 by = floor_size(cy, ncs), bx = floor_size(cx, ncs);
                 normal_code = 4;
@@ -609,7 +650,7 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
                 if (!in_range(bx, by, bz - 1)) return false;
                 cur.z += tz * d.z;
                 if (!in_range(cx, cy, bz - 1)) return false;
-                node = oct_chunk(nodes, oc.root, cx, cy, bz - 1);
+                node = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, cx, cy, bz - 1);
                 uint32_t ncs = node.kind_size >> 8;
                 bx = floor_size(cx, ncs), by = floor_size(cy, ncs);
                 bz -= 1 << ncs;
@@ -1804,7 +1845,8 @@ __global__ void __launch_bounds__(BLOCK, seg_waves(WAVE, FEAT)) k_segments(Scene
                 __builtin_amdgcn_readfirstlane((uint32_t)chunk_end);
     bool dry = false;  // the global counter has run past the end of the work
     CandLds cand_bits{nullptr, nullptr};
-    if constexpr (!WAVE) cand_bits = candidate_lds(sv);
+    // (kernels with octree code keep their LDS for the octree walk's ancestor cache)
+    if constexpr (!WAVE && (FEAT & FEAT_OCTREE) == 0) cand_bits = candidate_lds(sv);
     Stamps st{};
     REGION_BEGIN(total);
     for (uint32_t step = 0; step < rp.steps; ++step) {
@@ -2073,7 +2115,8 @@ __global__ void __launch_bounds__(BLOCK) k_trace_rays(SceneView sv, const double
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     Stamps st{};
     CandLds cand_bits{nullptr, nullptr};
-    if constexpr (!WAVE) cand_bits = candidate_lds(sv);
+    // (kernels with octree code keep their LDS for the octree walk's ancestor cache)
+    if constexpr (!WAVE && (FEAT & FEAT_OCTREE) == 0) cand_bits = candidate_lds(sv);
     bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g, live, h, st) : (live && nearest_hit_lane<FEAT>(sv, ray, g, h, st, cand_bits));
     if (!live) return;
     D3 n_w{0, 0, 0}, p_w{0, 0, 0};
@@ -2209,7 +2252,7 @@ constexpr int LEAF_LIST_MAX = 16;
 enum : int { TRAV_LANE = 1, TRAV_WAVE_TREE = 2, TRAV_WAVE_LEAVES = 3, TRAV_CANDIDATES = 4 };
 static int traversal_mode(const mrt_scene* sc) {
     const bool have_list = !sc->flat.leaf_recs.empty();
-    const bool have_cand = !sc->flat.cand_nodes.empty();
+    const bool have_cand = !sc->flat.cand_nodes.empty() && (sc->features & FEAT_OCTREE) == 0;
     if (sc->opt_traversal == TRAV_LANE || sc->opt_traversal == TRAV_WAVE_TREE) return (int)sc->opt_traversal;
     if (sc->opt_traversal == TRAV_WAVE_LEAVES) return have_list ? TRAV_WAVE_LEAVES : TRAV_WAVE_TREE;
     if (sc->opt_traversal == TRAV_CANDIDATES) return have_cand ? TRAV_CANDIDATES : TRAV_LANE;
