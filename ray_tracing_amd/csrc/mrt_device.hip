@@ -588,75 +588,29 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
         double ty = ((double)by + (double)step * sy - cur.y) * inv.y;
         double tz = ((double)bz + (double)step * sz - cur.z) * inv.z;
         if (tx < 0.0 || ty < 0.0 || tz < 0.0) return false;
-        DOctNode node;
-        int normal_code;
-        if (tx < ty && tx < tz) {
-            cur.y += tx * d.y;
-            cur.z += tx * d.z;
-            int32_t cy = f64_as_i32(cur.y), cz = f64_as_i32(cur.z);
-            if (d.x >= 0.0) {
-                bx += step * (__builtin_signbit(d.x) ? -1 : 1);
-                cur.x += tx * d.x;
-                if (!in_range(bx, cy, cz)) return false;
-                node = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, bx, cy, cz);
-                uint32_t ncs = node.kind_size >> 8;
-                by = floor_size(cy, ncs), bz = floor_size(cz, ncs);
-                normal_code = 0;
-            } else {
-                if (!in_range(bx - 1, by, bz)) return false;
-                cur.x += tx * d.x;
-                if (!in_range(bx - 1, cy, cz)) return false;  // get_chunk_size panics out of range
-                node = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, bx - 1, cy, cz);
-                uint32_t ncs = node.kind_size >> 8;
-                by = floor_size(cy, ncs), bz = floor_size(cz, ncs);
-                bx -= 1 << ncs;
-                normal_code = 1;
-            }
-        } else if (ty < tx && ty < tz) {
-            cur.x += ty * d.x;
-            cur.z += ty * d.z;
-            int32_t cx = f64_as_i32(cur.x), cz = f64_as_i32(cur.z);
-            if (d.y >= 0.0) {
-                by += step * (__builtin_signbit(d.y) ? -1 : 1);
-                cur.y += ty * d.y;
-                if (!in_range(cx, by, cz)) return false;
-                node = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, cx, by, cz);
-                uint32_t ncs = node.kind_size >> 8;
-                bx = floor_size(cx, ncs), bz = floor_size(cz, ncs);
-                normal_code = 2;
-            } else {
-                if (!in_range(bx, by - 1, bz)) return false;
-                cur.y += ty * d.y;
-                if (!in_range(cx, by - 1, cz)) return false;
-                node = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, cx, by - 1, cz);
-                uint32_t ncs = node.kind_size >> 8;
-                bx = floor_size(cx, ncs), bz = floor_size(cz, ncs);
-                by -= 1 << ncs;
-                normal_code = 3;
-            }
-        } else {  // ties fall into the z branch (ray_trace.rs:398)
-            cur.y += tz * d.y;
-            cur.x += tz * d.x;
-            int32_t cx = f64_as_i32(cur.x), cy = f64_as_i32(cur.y);
-            if (d.z >= 0.0) {
-                bz += step * (__builtin_signbit(d.z) ? -1 : 1);
-                cur.z += tz * d.z;
-                if (!in_range(cx, cy, bz)) return false;
-                node = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, cx, cy, bz);
-                uint32_t ncs = node.kind_size >> 8;
-                by = floor_size(cy, ncs), bx = floor_size(cx, ncs);
-                normal_code = 4;
-            } else {
-                if (!in_range(bx, by, bz - 1)) return false;
-                cur.z += tz * d.z;
-                if (!in_range(cx, cy, bz - 1)) return false;
-                node = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, cx, cy, bz - 1);
-                uint32_t ncs = node.kind_size >> 8;
-                bx = floor_size(cx, ncs), by = floor_size(cy, ncs);
-                bz -= 1 << ncs;
-                normal_code = 5;
-            }
-        }
+        // The reference has six copies of this step (axis x sign, ray_trace.rs:222-470); here the axis
+        // is a value, so the lanes of a wave take one path and issue one lookup together. The
+        // smallest t picks the axis, ties fall to z (ray_trace.rs:398).
+        const int axis = (tx < ty && tx < tz) ? 0 : ((ty < tx && ty < tz) ? 1 : 2);
+        const double tm = axis == 0 ? tx : (axis == 1 ? ty : tz);
+        const double da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+        const int32_t ba = axis == 0 ? bx : (axis == 1 ? by : bz);
+        cur.x += tm * d.x, cur.y += tm * d.y, cur.z += tm * d.z;
+        const int32_t cx = f64_as_i32(cur.x), cy = f64_as_i32(cur.y), cz = f64_as_i32(cur.z);
+        // forwards: the block coordinate moves by the step; backwards: the cell just below the block
+        const bool forward = da >= 0.0;
+        const int32_t la = forward ? ba + step * (__builtin_signbit(da) ? -1 : 1) : ba - 1;
+        const int32_t lx = axis == 0 ? la : cx, ly = axis == 1 ? la : cy, lz = axis == 2 ? la : cz;
+        // (backwards, the reference also checks the cell below the old block before it moves on)
+        if (!forward && !in_range(axis == 0 ? la : bx, axis == 1 ? la : by, axis == 2 ? la : bz)) return false;
+        if (!in_range(lx, ly, lz)) return false;  // get_chunk_size panics out of range
+        const DOctNode node = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, lx, ly, lz);
+        const uint32_t ncs = node.kind_size >> 8;
+        const int32_t na = forward ? la : ba - (1 << ncs);
+        bx = axis == 0 ? na : floor_size(cx, ncs);
+        by = axis == 1 ? na : floor_size(cy, ncs);
+        bz = axis == 2 ? na : floor_size(cz, ncs);
+        const int normal_code = axis * 2 + (forward ? 0 : 1);
         // handle_hit, ray_trace.rs:202-221
         if ((node.kind_size & 0xFF) == MRT_OCT_LEAF) {
             bool is_volume = false;
