@@ -429,21 +429,13 @@ __device__ __forceinline__ bool aabb_hit(D3 mn, D3 mx, const RayD& r, D3 inv_d, 
 
 // ============================================================== voxel octree (fast_oct_tree/)
 // Leaf / empty chunk that contains cell (x, y, z) (in range): get_chunk_size + get_chunk
-// (ray_trace.rs:23-83) in one root-to-leaf descent over the breadth-first node array.
-__device__ __forceinline__ DOctNode oct_chunk(const DOctNode* nodes, uint32_t root, int32_t x, int32_t y, int32_t z) {
-    DOctNode n = nodes[root];
-    while ((n.kind_size & 0xFF) == MRT_OCT_PARENT) {
-        uint32_t cs = (n.kind_size >> 8) - 1;
-        // Node::world_pos_to_child_index (mod.rs:217-225): child order x*4 + y*2 + z
-        uint32_t ci = ((((uint32_t)x >> cs) & 1u) << 2) | ((((uint32_t)y >> cs) & 1u) << 1) | (((uint32_t)z >> cs) & 1u);
-        n = nodes[(uint32_t)n.link + ci];
-    }
-    return n;
-}
-// The same lookup for a walk that moves from cell to neighbouring cell: the parents on the path to
-// the previous cell are remembered per lane (their child links, by size exponent, in LDS), and the
-// descent restarts at the smallest parent that also contains the new cell, which is one or two
-// levels up for most steps instead of the whole depth from the root. Same node as oct_chunk.
+// (ray_trace.rs:23-83) as one descent over the breadth-first node array; the child of a parent of
+// size exponent s is picked by bit s - 1 of the cell (Node::world_pos_to_child_index,
+// mod.rs:217-225: child order x*4 + y*2 + z).
+// The walk moves from cell to neighbouring cell, so the parents on the path to the previous cell
+// are remembered per lane (their child links, by size exponent, in LDS) and the descent restarts at
+// the smallest parent that also contains the new cell: one or two levels up for most steps
+// instead of the whole depth from the root.
 constexpr int OCT_ANC_LEVELS = 16;
 struct OctCursor {
     uint32_t* anc;      // this lane's column of a [OCT_ANC_LEVELS][BLOCK] array
@@ -558,14 +550,12 @@ __device__ __forceinline__ int oct_handle_empty(OctVolume& vs, D3 cur, D3 d, D3&
 template <bool VOL>
 __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels, const DOctree& oc, int32_t bx, int32_t by,
                                   int32_t bz, D3 origin, D3 d, int initial_normal, const Rng& g, uint32_t& entry, D3& hit_pos,
-                                  int& code, int& voxel) {
+                                  int& code, int& voxel, OctCursor& cursor) {
     const int32_t ws = (int32_t)(1u << oc.world_log2);
     auto in_range = [&](int32_t x, int32_t y, int32_t z) {
         return x >= 0 && x < ws && y >= 0 && y < ws && z >= 0 && z < ws;
     };
     if (!in_range(bx, by, bz)) return false;  // get_chunk(..).expect("out of range")
-    __shared__ uint32_t oct_anc[OCT_ANC_LEVELS * BLOCK];
-    OctCursor cursor{oct_anc + threadIdx.x, 0, 0, 0, 0, false};
     DOctNode chunk = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, bx, by, bz);
     uint32_t csz = chunk.kind_size >> 8;
     bx = floor_size(bx, csz), by = floor_size(by, csz), bz = floor_size(bz, csz);
@@ -637,9 +627,11 @@ template <bool VOL>
 __device__ bool oct_trace_ray(const DOctNode* nodes, const mrt_voxel* voxels, const DOctree& oc, D3 o, D3 d, const Rng& g,
                               uint32_t& entry, D3& hit_pos, int& code, int& voxel) {
     const double ws = (double)(1u << oc.world_log2);
+    __shared__ uint32_t oct_anc[OCT_ANC_LEVELS * BLOCK];
+    OctCursor cursor{oct_anc + threadIdx.x, 0, 0, 0, 0, false};
     if (o.x >= 0.0 && o.x <= ws && o.y >= 0.0 && o.y <= ws && o.z >= 0.0 && o.z <= ws) {
         return oct_ray_iteration<VOL>(nodes, voxels, oc, f64_as_i32(o.x), f64_as_i32(o.y), f64_as_i32(o.z), o, d, 1 /* unit_x */,
-                                      g, entry, hit_pos, code, voxel);
+                                      g, entry, hit_pos, code, voxel, cursor);
     }
     double v0 = (0.0 - o.x) / d.x, v1 = (ws - o.x) / d.x;
     double v2 = (0.0 - o.y) / d.y, v3 = (ws - o.y) / d.y;
@@ -667,7 +659,7 @@ __device__ bool oct_trace_ray(const DOctNode* nodes, const mrt_voxel* voxels, co
     const int32_t wsi = (int32_t)(1u << oc.world_log2);
     // self.get(block as u32): a negative coordinate wraps and is out of range -> None
     if (bx >= 0 && bx < wsi && by >= 0 && by < wsi && bz >= 0 && bz < wsi) {
-        DOctNode n = oct_chunk(nodes, oc.root, bx, by, bz);
+        DOctNode n = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, bx, by, bz);
         if ((n.kind_size & 0xFF) == MRT_OCT_LEAF) {
             bool is_volume = false;
             if constexpr (VOL) is_volume = voxels[n.link].kind == MRT_VOX_VOLUME;
@@ -679,7 +671,7 @@ __device__ bool oct_trace_ray(const DOctNode* nodes, const mrt_voxel* voxels, co
             }
         }
     }
-    return oct_ray_iteration<VOL>(nodes, voxels, oc, bx, by, bz, position, d, min_index, g, entry, hit_pos, code, voxel);
+    return oct_ray_iteration<VOL>(nodes, voxels, oc, bx, by, bz, position, d, min_index, g, entry, hit_pos, code, voxel, cursor);
 }
 
 // Hittable for FastOctTree<Voxel> (fast_oct_tree/hittable.rs:10-68); `sr` is the object-space ray.
