@@ -8,7 +8,9 @@ from tests.helpers import scene_by_name
 
 for name, W, H, spp in [("Cornell Smoke", 1920, 1080, 64), ("Random Scene", 800, 450, 64),
                         ("Light Demonstration", 1920, 1080, 64), ("Voxel City", 3840, 2160, 4),
-                        ("Fast Oct Tree Sphere", 1920, 1080, 16), ("Easy Cornell Box", 1920, 1080, 32)]:
+                        ("Fast Oct Tree Sphere", 1920, 1080, 16), ("Easy Cornell Box", 1920, 1080, 32),
+                        ("Random Scene", 1920, 1080, 32), ("Voxel City", 3840, 2160, 16), ("Easy Scene", 1920, 1080, 16),
+                        ("Fast Oct Tree Volume Ice", 1920, 1080, 16), ("Fast Oct Tree 2 density", 1920, 1080, 16)]:
     rt = RayTracer(scene_by_name(name), device=0, seed=0)
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     rt.render_device(accum.data_ptr(), W, H, 1)
