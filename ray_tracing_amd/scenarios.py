@@ -274,7 +274,60 @@ def voxel_city(building_vox, scale_roads: bool = True) -> WorldInfo:
     return WorldInfo([Object(grid.linearise())], [], bg, cam, sun=None)
 
 
+def new_demo(special_items) -> WorldInfo:
+    """world/demo.rs:12-67: a grey floor, a small bright sphere light (also the light list), the items, Sky(1)."""
+    look_at, origin = (0.0, 1.0, 0.0), (10.0, 10.0, 2.0)
+    floor = Object(XZRect(-5.0, 5.0, -5.0, 5.0, 0.0, Lambertian(SolidColor((0.5, 0.5, 0.5))), False))
+    light = Object(Sphere(0.2, (0.0, 3.0, 1.0), DiffuseLight(SolidColor((2000.0, 2000.0, 2000.0)))))
+    return WorldInfo([floor, light] + list(special_items), [Object(light.shape)], Sky(1.0),
+                     CameraInfo(1.0, 20.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
+def lambertian_demo() -> WorldInfo:
+    """world/demo/lambertian.rs ("Lambertian Demonstration")."""
+    return new_demo([Object(Sphere(1.0, (0.0, 1.0, 0.0), Lambertian(SolidColor((0.5, 0.1, 0.0)))))])
+
+
+def metallic_demo(fuzz: float) -> WorldInfo:
+    """world/demo/metalic_demo.rs ("Metallic Demonstration Smooth": fuzz 0, "... Rough": fuzz 0.8)."""
+    return new_demo([Object(Sphere(1.0, (0.0, 1.0, 0.0), Metal(SolidColor((0.5, 0.1, 0.0)), fuzz)))])
+
+
+def cube_field() -> WorldInfo:
+    """world/demo/cube_field.rs ("Cube Field"): two unit boxes, translated then rotated about y."""
+    boxes = [Object(RenderBox((-0.5, -0.5, -0.5), (0.5, 0.5, 0.5), Lambertian(SolidColor((0.5, 0.1, 0.0)))),
+                    Transform.identity().translate((x, 0.5, z)).rotate_y(deg))
+             for x, z, deg in [(-0.5, -0.6, 20.0), (0.6, 0.6, -2.0)]]
+    return new_demo(boxes)
+
+
+def dielectric_demo(refraction: float) -> WorldInfo:
+    """world/dielectric.rs ("Dielectric Demonstration, Low Refraction": 1.0, "... High Refraction": 1.5).
+    The camera's field of view is 1 degree there."""
+    look_at, origin = (0.0, 1.0, 0.0), (10.0, 10.0, 2.0)
+    floor = Object(XZRect(-5.0, 5.0, -5.0, 5.0, 0.0, Lambertian(SolidColor((0.5, 0.5, 0.5))), False))
+    glass = Object(Sphere(1.0, (0.0, 1.0, 0.0), Dielectric(refraction, (0.8, 0.8, 0.8))))
+    behind = Object(Sphere(1.0, (-1.0, 1.0, 1.0), Lambertian(SolidColor((0.5, 0.1, 0.0)))))
+    light = Object(Sphere(0.2, (0.0, 3.0, 1.0), DiffuseLight(SolidColor((2.0, 2.0, 2.0)))))
+    return WorldInfo([floor, light, behind, glass], [Object(light.shape)], Sky(0.3),
+                     CameraInfo(1.0, 1.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
+def empty_scene() -> WorldInfo:
+    """world/empty_scene.rs ("Empty Scene"): no objects, black background."""
+    look_at, origin = (0.0, 0.0, -1.0), (10.0, 3.0, 2.0)
+    return WorldInfo([], [], ConstantColor((0.0, 0.0, 0.0)),
+                     CameraInfo(1.0, 20.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
 SCENARIOS: Dict[str, Callable[[], WorldInfo]] = {
+    "Lambertian Demonstration": lambertian_demo,
+    "Metallic Demonstration Smooth": lambda: metallic_demo(0.0),
+    "Metallic Demonstration Rough": lambda: metallic_demo(0.8),
+    "Dielectric Demonstration, Low Refraction": lambda: dielectric_demo(1.0),
+    "Dielectric Demonstration, High Refraction": lambda: dielectric_demo(1.5),
+    "Cube Field": cube_field,
+    "Empty Scene": empty_scene,
     "Fast Oct Tree Sphere": fast_oct_tree_sphere,
     "Cornell Smoke": cornell_smoke,
     "Easy Cornell Box": easy_cornell_box,

@@ -14,6 +14,11 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @functools.lru_cache(maxsize=None)
+def golden_key(name: str) -> str:
+    """File stem of a scenario's golden vectors under tests/golden/."""
+    return name.lower().replace(",", "").replace(" ", "_")
+
+
 def scene_by_name(name: str) -> WorldInfo:
     if name == "Voxel City":
         return scenarios.voxel_city(scenarios.load_vox_fixture(os.path.join(GOLDEN_DIR, "skyscraper0_vox.npz")))

@@ -9,7 +9,7 @@ import pytest
 
 from ray_tracing_amd import scenarios
 from tests import oracle_ffi
-from tests.helpers import line_of_spheres, scene_by_name
+from tests.helpers import golden_key, line_of_spheres, scene_by_name
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MASK = (1 << 64) - 1
@@ -78,9 +78,11 @@ def test_cornell_bvh_shape():
 
 
 @pytest.mark.parametrize("name", ["Cornell Smoke", "Random Scene", "Light Demonstration", "Easy Cornell Box",
-                                  "Two Sphere", "Fast Oct Tree Sphere", "Voxel City"])
+                                  "Two Sphere", "Fast Oct Tree Sphere", "Voxel City", "Lambertian Demonstration",
+                                  "Metallic Demonstration Rough", "Dielectric Demonstration, High Refraction",
+                                  "Cube Field"])
 def test_fixed_rays_and_render_golden(name):
-    g = np.load(os.path.join(GOLD, name.lower().replace(" ", "_") + ".npz"))
+    g = np.load(os.path.join(GOLD, golden_key(name) + ".npz"))
     ow = oracle_ffi.OracleWorld(scene_by_name(name))
     obj, t, normal, pos, ff = ow.trace_rays(g["rays"], seed=11)
     assert (obj == g["obj"]).all()
