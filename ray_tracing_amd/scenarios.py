@@ -274,6 +274,65 @@ def voxel_city(building_vox, scale_roads: bool = True) -> WorldInfo:
     return WorldInfo([Object(grid.linearise())], [], bg, cam, sun=None)
 
 
+def explosion() -> WorldInfo:
+    """world/fast_oct_tree.rs:103-172 ("Fast Oct Tree Explosion"): a cosine height field of two colours under an
+    orange sphere light. The heights are f32 arithmetic there; numpy's f32 cos may differ from Rust's in the last
+    bit, which could move a column by one voxel where the height is within rounding of an integer."""
+    from .octree import OctTree
+    xs, zs = np.meshgrid(np.arange(100), np.arange(100), indexing="ij")
+    radius = np.sqrt((np.float32(50.0) - xs.astype(np.float32)) ** 2 + (np.float32(50.0) - zs.astype(np.float32)) ** 2,
+                     dtype=np.float32)
+    h = np.cos(radius / np.float32(10.0), dtype=np.float32) * np.float32(10.0) + np.float32(15.0)
+    h = np.minimum(np.maximum(h, np.float32(0.0)), np.float32(19.0)).astype(np.int64)      # `as isize` truncates
+    tree = OctTree()
+    cols = [(x, y, z) for x in range(100) for z in range(100) for y in range(int(h[x, z]) + 1)]
+    pts = np.asarray(cols, dtype=np.int64)
+    albedo = np.where((pts[:, 1] < 9)[:, None], np.float32([0.65, 0.8, 0.05])[None, :], np.float32([0.65, 0.05, 0.05])[None, :])
+    tree.set_many(pts, albedo)
+    origin, look_at = (-20.0, 50.0, -20.0), (50.0, 10.0, 50.0)
+    e = [float(np.float32(20000.0) * (np.float32(c) / np.float32(255.0))) for c in (252.0, 79.0, 5.0)]
+    light = Object(Sphere(3.0, (50.0, 28.0, 50.0), DiffuseLight(SolidColor(tuple(e)))))
+    return WorldInfo([Object(tree.linearise()), light], [Object(light.shape)], Sky(0.1),
+                     CameraInfo(1.0, 40.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
+def cube_world() -> WorldInfo:
+    """world/fast_oct_tree.rs:173-244 ("Fast Oct Tree Cubeworld"): a 3 x 3 x 3 block and three single voxels."""
+    from .octree import OctTree, box_points
+    tree = OctTree()
+    red = np.float32([0.65, 0.05, 0.05])
+    tree.set_many(box_points((3, 3, 3), (6, 6, 6)), red)
+    tree.set_many(np.asarray([(0, 0, 0), (0, 1, 0), (5, 5, 5)]), red)
+    origin, look_at = (-20.0, 5.0, -20.0), (0.0, 5.0, 5.0)
+    light = Object(Sphere(1.0, (10.0, 10.0, -10.0), DiffuseLight(SolidColor((20000.0, 20000.0, 20000.0)))))
+    return WorldInfo([Object(tree.linearise()), light], [Object(light.shape)], ConstantColor((0.1, 0.1, 0.1)),
+                     CameraInfo(1.0, 40.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
+def gold_cube() -> WorldInfo:
+    """world/fast_oct_tree.rs:692-786 ("Fast Oct Tree Gold Cube"): three reflecting 16^3 cubes of fuzz 0.8, 0.4 and
+    0.1 on a 128 x 128 floor."""
+    from .octree import OctTree, box_points, solid_lambertian, solid_reflect
+    tree = OctTree()
+    tree.set_rows(box_points((0, 0, 0), (128, 1, 128)), solid_lambertian((0.8, 0.8, 0.8)))
+    gold = (1.0, float(np.float32(254.0) / np.float32(255.0)), 0.0)
+    for x, fuzz in [(30, 0.8), (60, 0.4), (90, 0.1)]:
+        tree.set_rows(box_points((x, 1, 64), (x + 16, 17, 80)), solid_reflect(gold, fuzz))
+    origin, look_at = (64.0, 100.0, -300.0), (64.0, 0.0, 64.0)
+    light = Object(Sphere(10.0, (-100.0, 50.0, -100.0), DiffuseLight(SolidColor((100.0, 100.0, 100.0)))))
+    return WorldInfo([Object(tree.linearise()), light], [Object(light.shape)], ConstantColor((0.1, 0.1, 0.1)),
+                     CameraInfo(1.0, 20.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
+def apartment_building(building_vox) -> WorldInfo:
+    """world/fast_oct_tree.rs:787-817 ("Fast Oct Tree Apartment Building"): voxel_assets/apartment_building.vox
+    under Sky(0.4), no lights."""
+    from .octree import load_vox
+    origin, look_at = (-50.0, 100.0, -40.0), (30.0, 10.0, 30.0)
+    return WorldInfo([Object(load_vox(building_vox).linearise())], [], Sky(0.4),
+                     CameraInfo(1.0, 40.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
 def new_demo(special_items) -> WorldInfo:
     """world/demo.rs:12-67: a grey floor, a small bright sphere light (also the light list), the items, Sky(1)."""
     look_at, origin = (0.0, 1.0, 0.0), (10.0, 10.0, 2.0)
@@ -328,6 +387,9 @@ SCENARIOS: Dict[str, Callable[[], WorldInfo]] = {
     "Dielectric Demonstration, High Refraction": lambda: dielectric_demo(1.5),
     "Cube Field": cube_field,
     "Empty Scene": empty_scene,
+    "Fast Oct Tree Explosion": explosion,
+    "Fast Oct Tree Cubeworld": cube_world,
+    "Fast Oct Tree Gold Cube": gold_cube,
     "Fast Oct Tree Sphere": fast_oct_tree_sphere,
     "Cornell Smoke": cornell_smoke,
     "Easy Cornell Box": easy_cornell_box,

@@ -10,7 +10,8 @@ sys.path.insert(0, ROOT)
 from ray_tracing_amd.octree import parse_vox  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
-for name, path in [("skyscraper0", "voxel_assets/city/skyscraper0.vox"), ("vox_2x2", "voxel_assets/2x2.vox")]:
+for name, path in [("skyscraper0", "voxel_assets/city/skyscraper0.vox"), ("vox_2x2", "voxel_assets/2x2.vox"),
+                   ("apartment_building", "voxel_assets/apartment_building.vox")]:
     vox = parse_vox(open(os.path.join("/root/reference", path), "rb").read())
     sizes = np.array([len(m) for m in vox.models], dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, name + "_vox.npz"), xyzi=np.concatenate(vox.models), model_sizes=sizes,

@@ -22,6 +22,8 @@ def golden_key(name: str) -> str:
 def scene_by_name(name: str) -> WorldInfo:
     if name == "Voxel City":
         return scenarios.voxel_city(scenarios.load_vox_fixture(os.path.join(GOLDEN_DIR, "skyscraper0_vox.npz")))
+    if name == "Fast Oct Tree Apartment Building":
+        return scenarios.apartment_building(scenarios.load_vox_fixture(os.path.join(GOLDEN_DIR, "apartment_building_vox.npz")))
     return scenarios.build(name)
 
 

@@ -25,7 +25,9 @@ SCENES = ["Cornell Smoke", "Random Scene", "Light Demonstration", "Easy Cornell 
           "Fast Oct Tree Sphere", "Voxel City", "Easy Scene", "Fast Oct Tree 2 density",
           "Fast Oct Tree Volume Lambertian", "Fast Oct Tree Volume Metal", "Fast Oct Tree Volume Ice",
           "Lambertian Demonstration", "Metallic Demonstration Smooth", "Metallic Demonstration Rough",
-          "Dielectric Demonstration, Low Refraction", "Dielectric Demonstration, High Refraction", "Cube Field"]
+          "Dielectric Demonstration, Low Refraction", "Dielectric Demonstration, High Refraction", "Cube Field",
+          "Fast Oct Tree Explosion", "Fast Oct Tree Cubeworld", "Fast Oct Tree Gold Cube",
+          "Fast Oct Tree Apartment Building"]
 T_RTOL = 1e-5      # north star: within 1e-5 relative hit t and normals
 N_ATOL = 1e-5
 

@@ -80,7 +80,8 @@ def test_cornell_bvh_shape():
 @pytest.mark.parametrize("name", ["Cornell Smoke", "Random Scene", "Light Demonstration", "Easy Cornell Box",
                                   "Two Sphere", "Fast Oct Tree Sphere", "Voxel City", "Lambertian Demonstration",
                                   "Metallic Demonstration Rough", "Dielectric Demonstration, High Refraction",
-                                  "Cube Field"])
+                                  "Cube Field", "Fast Oct Tree Explosion", "Fast Oct Tree Gold Cube",
+                                  "Fast Oct Tree Apartment Building"])
 def test_fixed_rays_and_render_golden(name):
     g = np.load(os.path.join(GOLD, golden_key(name) + ".npz"))
     ow = oracle_ffi.OracleWorld(scene_by_name(name))
