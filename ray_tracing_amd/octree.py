@@ -259,6 +259,20 @@ def load_vox(vox: VoxFile) -> OctTree:
     return tree
 
 
+def load_map(tiles, tile_size: int, models) -> OctTree:
+    """FastOctTree::load_map (operations/load.rs:28-67): `tiles[x][z]` names a tile type; `models` maps a type to
+    its VoxFile (types without a model are air). Tile (x, z) is combined at ((len - x - 1) * tile_size, 0,
+    z * tile_size), in x-major order, later tiles overwriting earlier ones."""
+    trees = {k: load_vox(v) for k, v in models.items()}
+    tree = OctTree()
+    for x in range(len(tiles)):
+        for z in range(len(tiles[x])):
+            tile = trees.get(int(tiles[x][z]))
+            if tile is not None:
+                tree.combine(tile, ((len(tiles) - x - 1) * tile_size, 0, z * tile_size))
+    return tree
+
+
 def box_points(start, end) -> np.ndarray:
     """IterBox::from_xyz(end).start_xyz(start) (cpu_rt/src/prelude.rs:19-77): x-major, z innermost."""
     # BoxIter::next (prelude.rs:57-77) stops on x alone; y and z emit their start value even when the

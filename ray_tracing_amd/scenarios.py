@@ -333,6 +333,30 @@ def apartment_building(building_vox) -> WorldInfo:
                      CameraInfo(1.0, 40.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
 
 
+def load_map_fixture(path: str):
+    """Reads a decoded tile map (tests/golden/sinnoh_map.npz: the .yml's tile table and the .vox models it names)
+    back into (tiles, tile_size, {tile type: VoxFile})."""
+    from .octree import VoxFile
+    z = np.load(path)
+    models = {}
+    for k in z["model_types"]:
+        sizes, xyzi, pos, ms = z[f"m{int(k)}_sizes"], z[f"m{int(k)}_xyzi"], 0, []
+        for n in sizes:
+            ms.append(xyzi[pos:pos + int(n)])
+            pos += int(n)
+        models[int(k)] = VoxFile(ms, z[f"m{int(k)}_palette"])
+    return z["tiles"], int(z["tile_size"]), models
+
+
+def sinnoh(tiles, tile_size: int, models) -> WorldInfo:
+    """world/fast_oct_tree.rs:64-102 ("Fast Oct Tree Sinnoh"): the 32 x 32 tile map voxel_assets/sinnoh/twinleaf.yml
+    under Sky(0.6), no lights."""
+    from .octree import load_map
+    origin, look_at = (-500.0, 300.0, 256.0), (256.0, 10.0, 256.0)
+    return WorldInfo([Object(load_map(tiles, tile_size, models).linearise())], [], Sky(0.6),
+                     CameraInfo(1.0, 40.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
 def new_demo(special_items) -> WorldInfo:
     """world/demo.rs:12-67: a grey floor, a small bright sphere light (also the light list), the items, Sky(1)."""
     look_at, origin = (0.0, 1.0, 0.0), (10.0, 10.0, 2.0)

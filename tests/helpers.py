@@ -24,6 +24,8 @@ def scene_by_name(name: str) -> WorldInfo:
         return scenarios.voxel_city(scenarios.load_vox_fixture(os.path.join(GOLDEN_DIR, "skyscraper0_vox.npz")))
     if name == "Fast Oct Tree Apartment Building":
         return scenarios.apartment_building(scenarios.load_vox_fixture(os.path.join(GOLDEN_DIR, "apartment_building_vox.npz")))
+    if name == "Fast Oct Tree Sinnoh":
+        return scenarios.sinnoh(*scenarios.load_map_fixture(os.path.join(GOLDEN_DIR, "sinnoh_map.npz")))
     return scenarios.build(name)
 
 
