@@ -1,0 +1,129 @@
+// Test driver: runs the host-side scene flattening (reference-topology tree, node records, candidate
+// tree with its ancestor table) on random many-object scenes under the address and undefined-
+// behaviour sanitizers, and checks the structural invariants of the candidate tree.
+// Built and run by tests/test_host_logic.py; not part of the library.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../ray_tracing_amd/csrc/mrt_internal.h"
+
+namespace mrt {
+void set_last_error(const std::string&) {}
+}  // namespace mrt
+
+static int fail(const char* what, int scene) {
+    std::fprintf(stderr, "FAILED scene %d: %s\n", scene, what);
+    return 1;
+}
+
+int main() {
+    std::mt19937_64 rng(7);
+    auto uni = [&](double a, double b) { return std::uniform_real_distribution<double>(a, b)(rng); };
+    for (int scene = 0; scene < 40; ++scene) {
+        const int n = scene < 4 ? scene + 1 : 2 + (int)(rng() % 520);
+        std::vector<mrt_texture> tex(1);
+        tex[0] = mrt_texture{};
+        tex[0].kind = MRT_TEX_SOLID;
+        std::vector<mrt_material> mat(1);
+        mat[0] = mrt_material{};
+        mat[0].kind = MRT_MAT_LAMBERTIAN;
+        std::vector<mrt_shape> shapes;
+        std::vector<mrt_object> objects;
+        const bool with_medium = scene % 9 == 8;
+        for (int i = 0; i < n; ++i) {
+            mrt_shape s{};
+            s.material = 0, s.boundary = -1, s.octree = -1;
+            const int k = (int)(rng() % 6);
+            const double c[3] = {uni(-12, 12), uni(0, 2), uni(-12, 12)};
+            if (k <= 1) {
+                s.kind = MRT_SHAPE_SPHERE;
+                s.p[0] = (rng() % 17 == 0 ? -1.0 : 1.0) * uni(0.1, 0.6);
+                s.p[1] = c[0], s.p[2] = c[1], s.p[3] = c[2];
+            } else if (k <= 3) {
+                s.kind = MRT_SHAPE_MOVING_SPHERE;
+                s.p[0] = uni(0.1, 0.6);
+                for (int a = 0; a < 3; ++a) s.p[1 + a] = c[a], s.p[4 + a] = c[a] + uni(-0.5, 0.5);
+                s.p[7] = uni(-1, 0.5), s.p[8] = s.p[7] + uni(0.2, 2.0);
+            } else if (k == 4) {
+                s.kind = MRT_SHAPE_RENDER_BOX;
+                for (int a = 0; a < 3; ++a) s.p[a] = c[a] - 0.3, s.p[3 + a] = c[a] + uni(0.1, 0.5);
+            } else {
+                s.kind = MRT_SHAPE_XZ_RECT;
+                s.p[0] = c[0] - 0.5, s.p[1] = c[0] + 0.5, s.p[2] = c[2] - 0.5, s.p[3] = c[2] + 0.5, s.p[4] = c[1], s.p[5] = 1.0;
+            }
+            shapes.push_back(s);
+            if (with_medium && i == n / 2 && (s.kind == MRT_SHAPE_SPHERE || s.kind == MRT_SHAPE_RENDER_BOX)) {
+                mrt_shape m{};
+                m.kind = MRT_SHAPE_CONSTANT_MEDIUM, m.material = 0, m.boundary = (int32_t)shapes.size() - 1, m.octree = -1;
+                m.p[0] = 0.3;
+                shapes.push_back(m);
+            }
+            mrt_object o{};
+            o.shape = (int32_t)shapes.size() - 1;
+            const double ang = rng() % 3 == 0 ? uni(-1, 1) : 0.0, cs = std::cos(ang), sn = std::sin(ang);
+            const double m16[16] = {cs, 0, -sn, 0, 0, 1, 0, 0, sn, 0, cs, 0, uni(-1, 1), 0, uni(-1, 1), 1};  // column-major
+            for (int a = 0; a < 16; ++a) o.world_transform[a] = m16[a];
+            objects.push_back(o);
+        }
+        mrt_scene_desc d{};
+        d.abi_version = MRT_ABI_VERSION;
+        d.n_textures = 1, d.textures = tex.data();
+        d.n_materials = 1, d.materials = mat.data();
+        d.n_shapes = (uint32_t)shapes.size(), d.shapes = shapes.data();
+        d.n_objects = (uint32_t)objects.size(), d.objects = objects.data();
+        d.camera = mrt_camera_info{1.0, 40.0, {16, 4, 5}, {0, 0.5, 0}, {0, 1, 0}, 0.01, 14.0, 0.0, 1.0};
+        d.background.kind = MRT_BG_SKY, d.background.intensity = 1.0;
+        d.bvh_seed = (uint64_t)scene;
+        mrt::FlatScene f;
+        std::string err;
+        if (mrt::flatten_scene(&d, &f, &err) != MRT_OK) return fail(err.c_str(), scene);
+
+        // reference-topology tree: pre-order, skip links inside the array
+        const int nn = (int)f.nodes.size();
+        for (int i = 0; i < nn; ++i)
+            if (f.nodes[i].skip <= i || f.nodes[i].skip > nn) return fail("skip link", scene);
+        bool stochastic = false;
+        for (const auto& s : shapes) stochastic = stochastic || s.kind == MRT_SHAPE_CONSTANT_MEDIUM;
+        if (stochastic || nn > mrt::CAND_MAX_NODES) {
+            if (!f.cand_nodes.empty()) return fail("candidate tree built for a scene that does not qualify", scene);
+            continue;
+        }
+        if (f.cand_nodes.empty()) return fail("no candidate tree", scene);
+        // every leaf of the tree appears exactly once among the candidate tree's leaves, and its row
+        // of the ancestor table is the chain leaf -> root
+        int leaves = 0;
+        for (int i = 0; i < nn; ++i) leaves += f.nodes[i].object >= 0;
+        std::vector<int> seen((size_t)leaves, 0);
+        for (const mrt::DCand4& c : f.cand_nodes) {
+            for (int k = 0; k < 4; ++k) {
+                const int ch = c.child[k];
+                if (ch >= 0 && ch >= (int)f.cand_nodes.size()) return fail("child index", scene);
+                if (ch <= -2) {
+                    const int row = -2 - ch;
+                    if (row >= leaves || seen[(size_t)row]++) return fail("leaf row", scene);
+                    for (int a = 0; a < 3; ++a)
+                        if (!(c.lo[a][k] <= c.hi[a][k])) return fail("leaf box", scene);
+                }
+            }
+        }
+        for (int r = 0; r < leaves; ++r) {
+            if (!seen[(size_t)r]) return fail("leaf missing from the candidate tree", scene);
+            const int32_t* row = f.cand_chain.data() + (size_t)r * (size_t)f.cand_depth;
+            if (row[0] < 0 || row[0] >= nn || f.nodes[row[0]].object < 0) return fail("row does not start at a leaf", scene);
+            int k = 1;
+            for (; k < f.cand_depth && row[k] >= 0; ++k) {
+                const mrt::DNode& a = f.nodes[row[k]];
+                if (a.object >= 0 || !(row[k] < row[k - 1] && row[k - 1] < a.skip)) return fail("ancestor chain", scene);
+            }
+            if (row[k - 1] != 0 && nn > 1) return fail("chain does not reach the root", scene);
+            for (; k < f.cand_depth; ++k)
+                if (row[k] != -1) return fail("row padding", scene);
+        }
+    }
+    std::puts("host flattening: 40 scenes ok");
+    return 0;
+}
