@@ -125,5 +125,45 @@ int main() {
         }
     }
     std::puts("host flattening: 40 scenes ok");
+
+    // the native octree builder: random sets with overwrites, combine with negative offsets, linearise
+    for (int round = 0; round < 12; ++round) {
+        mrt_voxel_grid* a = mrt_voxels_create();
+        mrt_voxel_grid* b = mrt_voxels_create();
+        const int extent = 1 << (1 + round % 7);
+        std::vector<int32_t> xyz;
+        std::vector<mrt_voxel> vox;
+        const int count = 1 + (int)(rng() % 4000);
+        for (int i = 0; i < count; ++i) {
+            for (int k = 0; k < 3; ++k) xyz.push_back((int32_t)(rng() % (uint64_t)extent));
+            mrt_voxel v{};
+            v.kind = MRT_VOX_LAMBERTIAN;
+            v.albedo[0] = (float)(rng() % 3) * 0.25f, v.albedo[1] = 0.5f, v.albedo[2] = 0.5f;
+            vox.push_back(v);
+        }
+        if (mrt_voxels_set(a, xyz.data(), vox.data(), (size_t)count, 0) != MRT_OK) return fail("voxels_set", round);
+        if (mrt_voxels_set(b, xyz.data(), vox.data(), (size_t)(count / 2 + 1), 1) != MRT_OK) return fail("voxels_set one", round);
+        const int32_t off[3] = {(int32_t)(rng() % 9) - 4, (int32_t)(rng() % 9) - 4, (int32_t)(rng() % 40)};
+        if (mrt_voxels_combine(a, b, off) != MRT_OK) return fail("voxels_combine", round);
+        mrt_octree oc{};
+        if (mrt_voxels_linearise(a, &oc) != MRT_OK) return fail("voxels_linearise", round);
+        if (oc.n_nodes == 0 || oc.root >= oc.n_nodes || oc.n_children % 8 != 0) return fail("octree header", round);
+        size_t leaves_volume = 0;
+        for (uint32_t i = 0; i < oc.n_nodes; ++i) {
+            const mrt_oct_node& nd = oc.nodes[i];
+            if (nd.kind == MRT_OCT_PARENT) {
+                if (nd.first_child < 0 || (uint32_t)nd.first_child + 8 > oc.n_children) return fail("child block", round);
+                for (int k = 0; k < 8; ++k)
+                    if (oc.children[nd.first_child + k] >= oc.n_nodes) return fail("child index", round);
+            } else if (nd.kind == MRT_OCT_LEAF) {
+                if (nd.voxel < 0 || (uint32_t)nd.voxel >= oc.n_voxels) return fail("voxel index", round);
+                leaves_volume += (size_t)1 << (3 * nd.size);
+            }
+        }
+        if (leaves_volume != mrt_voxels_count(a)) return fail("leaf volume differs from the voxel count", round);
+        mrt_voxels_destroy(a);
+        mrt_voxels_destroy(b);
+    }
+    std::puts("octree builder: 12 rounds ok");
     return 0;
 }

@@ -62,8 +62,8 @@ def test_transform_composition_matches_reference_order():
 
 def test_flattening_under_sanitizers(tmp_path):
     """Host-side flattening (reference-topology tree, candidate tree, ancestor table) of 40 random many-object
-    scenes, compiled with the address and undefined-behaviour sanitizers; the driver also checks the candidate
-    tree's structural invariants."""
+    scenes and the native octree builder (set / combine / linearise), compiled with the address and
+    undefined-behaviour sanitizers; the driver also checks structural invariants of what they produce."""
     import shutil
     import subprocess
     if shutil.which("g++") is None:
@@ -72,7 +72,8 @@ def test_flattening_under_sanitizers(tmp_path):
     exe = str(tmp_path / "host_sanitized")
     subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                     "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "host_sanitized_driver.cpp"),
-                    os.path.join(root, "ray_tracing_amd", "csrc", "mrt_host.cpp"), "-o", exe], check=True, timeout=300)
+                    os.path.join(root, "ray_tracing_amd", "csrc", "mrt_host.cpp"),
+                    os.path.join(root, "ray_tracing_amd", "csrc", "mrt_octree.cpp"), "-o", exe], check=True, timeout=300)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "40 scenes ok" in out.stdout
+    assert "40 scenes ok" in out.stdout and "octree builder: 12 rounds ok" in out.stdout
