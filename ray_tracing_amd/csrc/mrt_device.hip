@@ -471,11 +471,12 @@ __device__ __forceinline__ DOctNode oct_chunk_near(const DOctNode* nodes, uint32
     c.valid = world_log2 < (uint32_t)OCT_ANC_LEVELS;
     return n;
 }
-__device__ __forceinline__ int32_t f64_as_i32(double v) {  // Rust `as i32`: toward zero, saturating, NaN -> 0
-    if (v != v) return 0;
-    if (v >= 2147483647.0) return 2147483647;
-    if (v <= -2147483648.0) return (int32_t)0x80000000;
-    return (int32_t)v;
+// Rust `as i32`: toward zero, saturating, NaN -> 0 -- which is what v_cvt_i32_f64 does by itself
+// (a C++ cast leaves the out-of-range cases undefined, hence the instruction by name).
+__device__ __forceinline__ int32_t f64_as_i32(double v) {
+    int32_t r;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(v));
+    return r;
 }
 __device__ __forceinline__ int32_t floor_size(int32_t v, uint32_t s) { return (v >> s) << s; }  // ray_trace.rs:686-688
 
