@@ -552,9 +552,9 @@ template <bool VOL>
 __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels, const DOctree& oc, int32_t bx, int32_t by,
                                   int32_t bz, D3 origin, D3 d, int initial_normal, const Rng& g, uint32_t& entry, D3& hit_pos,
                                   int& code, int& voxel, OctCursor& cursor) {
-    const int32_t ws = (int32_t)(1u << oc.world_log2);
-    auto in_range = [&](int32_t x, int32_t y, int32_t z) {
-        return x >= 0 && x < ws && y >= 0 && y < ws && z >= 0 && z < ws;
+    const uint32_t ws = 1u << oc.world_log2;
+    auto in_range = [&](int32_t x, int32_t y, int32_t z) {  // 0 <= v < ws, negative values wrap above ws
+        return (uint32_t)x < ws && (uint32_t)y < ws && (uint32_t)z < ws;
     };
     if (!in_range(bx, by, bz)) return false;  // get_chunk(..).expect("out of range")
     DOctNode chunk = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, bx, by, bz);
@@ -569,15 +569,16 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
                 return true;
         }
     }
-    const double sx = __builtin_signbit(d.x) ? 0.0 : 1.0, sy = __builtin_signbit(d.y) ? 0.0 : 1.0,
-                 sz = __builtin_signbit(d.z) ? 0.0 : 1.0;
+    // the far face of the block on each axis: block + step for a non-negative direction component
+    // (ray_trace.rs adds step * 1.0 or step * 0.0 in floating point; same integer either way)
+    const bool px = !__builtin_signbit(d.x), py = !__builtin_signbit(d.y), pz = !__builtin_signbit(d.z);
     const D3 inv{rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z)};
     int32_t step = 1 << csz;  // get_step_size of the current block
     for (int it = 0; it < 3000; ++it) {
-        if (!in_range(bx, by, bz)) return false;
-        double tx = ((double)bx + (double)step * sx - cur.x) * inv.x;
-        double ty = ((double)by + (double)step * sy - cur.y) * inv.y;
-        double tz = ((double)bz + (double)step * sz - cur.z) * inv.z;
+        // (the block is in range here: checked on entry, and every step below ends in a checked cell's block)
+        double tx = ((double)(bx + (px ? step : 0)) - cur.x) * inv.x;
+        double ty = ((double)(by + (py ? step : 0)) - cur.y) * inv.y;
+        double tz = ((double)(bz + (pz ? step : 0)) - cur.z) * inv.z;
         if (tx < 0.0 || ty < 0.0 || tz < 0.0) return false;
         // The reference has six copies of this step (axis x sign, ray_trace.rs:222-470); here the axis
         // is a value, so the lanes of a wave take one path and issue one lookup together. The
