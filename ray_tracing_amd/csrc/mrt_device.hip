@@ -572,6 +572,7 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
     // the far face of the block on each axis: block + step for a non-negative direction component
     // (ray_trace.rs adds step * 1.0 or step * 0.0 in floating point; same integer either way)
     const bool px = !__builtin_signbit(d.x), py = !__builtin_signbit(d.y), pz = !__builtin_signbit(d.z);
+    const bool fx = d.x >= 0.0, fy = d.y >= 0.0, fz = d.z >= 0.0;
     const D3 inv{rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z)};
     int32_t step = 1 << csz;  // get_step_size of the current block
     for (int it = 0; it < 3000; ++it) {
@@ -583,26 +584,27 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
         // The reference has six copies of this step (axis x sign, ray_trace.rs:222-470); here the axis
         // is a value, so the lanes of a wave take one path and issue one lookup together. The
         // smallest t picks the axis, ties fall to z (ray_trace.rs:398).
-        const int axis = (tx < ty && tx < tz) ? 0 : ((ty < tx && ty < tz) ? 1 : 2);
-        const double tm = axis == 0 ? tx : (axis == 1 ? ty : tz);
-        const double da = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
-        const int32_t ba = axis == 0 ? bx : (axis == 1 ? by : bz);
+        const bool ax0 = tx < ty && tx < tz, ax1 = !ax0 && ty < tx && ty < tz, ax2 = !ax0 && !ax1;
+        const double tm = ax2 ? tz : fmin(tx, ty);  // x or y win only as the strict minimum
+        const int32_t ba = ax0 ? bx : (ax1 ? by : bz);
         cur.x += tm * d.x, cur.y += tm * d.y, cur.z += tm * d.z;
         const int32_t cx = f64_as_i32(cur.x), cy = f64_as_i32(cur.y), cz = f64_as_i32(cur.z);
-        // forwards: the block coordinate moves by the step; backwards: the cell just below the block
-        const bool forward = da >= 0.0;
-        const int32_t la = forward ? ba + step * (__builtin_signbit(da) ? -1 : 1) : ba - 1;
-        const int32_t lx = axis == 0 ? la : cx, ly = axis == 1 ? la : cy, lz = axis == 2 ? la : cz;
-        // (backwards, the reference also checks the cell below the old block before it moves on)
-        if (!forward && !in_range(axis == 0 ? la : bx, axis == 1 ? la : by, axis == 2 ? la : bz)) return false;
-        if (!in_range(lx, ly, lz)) return false;  // get_chunk_size panics out of range
+        // forwards (component >= 0, which includes -0.0): the block coordinate moves by the step, whose
+        // sign follows the sign bit; backwards: the cell just below the block
+        const bool forward = (ax0 && fx) || (ax1 && fy) || (ax2 && fz);
+        const bool plus = (ax0 && px) || (ax1 && py) || (ax2 && pz);
+        const int32_t la = forward ? ba + (plus ? step : -step) : ba - 1;
+        const int32_t lx = ax0 ? la : cx, ly = ax1 ? la : cy, lz = ax2 ? la : cz;
+        // get_chunk_size panics out of range; this also covers the reference's earlier check of the
+        // cell below the old block on the way back (the other two coordinates are the block's own)
+        if (!in_range(lx, ly, lz)) return false;
         const DOctNode node = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, lx, ly, lz);
         const uint32_t ncs = node.kind_size >> 8;
         const int32_t na = forward ? la : ba - (1 << ncs);
-        bx = axis == 0 ? na : floor_size(cx, ncs);
-        by = axis == 1 ? na : floor_size(cy, ncs);
-        bz = axis == 2 ? na : floor_size(cz, ncs);
-        const int normal_code = axis * 2 + (forward ? 0 : 1);
+        bx = ax0 ? na : floor_size(cx, ncs);
+        by = ax1 ? na : floor_size(cy, ncs);
+        bz = ax2 ? na : floor_size(cz, ncs);
+        const int normal_code = (ax0 ? 0 : (ax1 ? 2 : 4)) + (forward ? 0 : 1);
         // handle_hit, ray_trace.rs:202-221
         if ((node.kind_size & 0xFF) == MRT_OCT_LEAF) {
             bool is_volume = false;
