@@ -886,6 +886,8 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
                                        Stamps& st) {
     D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
     LDS_AS uint32_t* bits = lds.bits;
+    uint32_t touched = 0;  // which words of the bit array hold marks (CAND_WORDS <= 32)
+    static_assert(CAND_WORDS <= 32, "one summary bit per word");
     const CandRay cr{{inv_d.x, inv_d.y, inv_d.z}, {ray.o.x * inv_d.x, ray.o.y * inv_d.y, ray.o.z * inv_d.z}, ray.time,
                      ray.time < 0.0 ? 1 : 0};
     REGION_BEGIN(search);
@@ -915,9 +917,11 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
                     const int n4[4] = {c.x, c.y, c.z, c.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (n4[e] >= 0)
+                        if (n4[e] >= 0) {
                             (void)__hip_atomic_fetch_or(bits + (n4[e] >> 5) * BLOCK, 1u << (n4[e] & 31), __ATOMIC_RELAXED,
                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+                            touched |= 1u << (n4[e] >> 5);
+                        }
                 }
             }
             if (next < 0) {
@@ -932,17 +936,17 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
     LaneWalk w{(double)FLT_MAX, -1, 0, {0.0, 0.0, 0.0}, 0, 0};
     // The marked nodes are known before any of them is visited, so the next node's record is
     // requested while the current one is processed (the walk is bound by load latency).
-    const int words = sv.n_cand_words;
     int wd = 0;
     uint32_t m = 0;
     auto next_marked = [&]() -> int {  // ascending node indices; clears the words it reads
-        while (m == 0) {
-            if (wd >= words) return -1;
+        if (m == 0) {
+            if (touched == 0) return -1;
+            wd = __ffs((int)touched) - 1;
+            touched &= touched - 1;
             m = bits[wd * BLOCK];
-            if (m) bits[wd * BLOCK] = 0;
-            ++wd;
+            bits[wd * BLOCK] = 0;
         }
-        const int idx = (wd - 1) * 32 + __ffs((int)m) - 1;
+        const int idx = wd * 32 + __ffs((int)m) - 1;
         m &= m - 1;
         return idx;
     };
