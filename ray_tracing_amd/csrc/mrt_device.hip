@@ -125,6 +125,7 @@ struct RenderParams {
     uint64_t seed, first_sample;
     uint32_t n_slots;
     uint32_t steps;
+    uint32_t chunk;  // work items a wave claims at a time
     double inv_npix_strip, inv_strip_w;  // reciprocals for the work-index decomposition
 };
 
@@ -1823,12 +1824,12 @@ __global__ void __launch_bounds__(BLOCK, seg_waves(WAVE, FEAT)) k_segments(Scene
                     unsigned long long base = 0;
                     const int leader = __ffsll((long long)mask) - 1;
                     REGION_BEGIN(claim);
-                    if ((int)lane_id() == leader) base = atomicAdd(&ctr->work_next, (unsigned long long)WORK_CHUNK);
+                    if ((int)lane_id() == leader) base = atomicAdd(&ctr->work_next, (unsigned long long)rp.chunk);
                     base = __shfl(base, leader, 64);
                     REGION_END(st, ST_CLAIM, claim);
                     if (base < rp.n_work) {
                         nb = base;
-                        ne = base + WORK_CHUNK < rp.n_work ? base + WORK_CHUNK : rp.n_work;
+                        ne = base + rp.chunk < rp.n_work ? base + rp.chunk : rp.n_work;
                     } else {
                         dry = true;
                     }
@@ -2157,6 +2158,7 @@ struct mrt_scene {
     int64_t opt_trace_zero = 0;
     int64_t opt_compact = 1;
     int64_t opt_shader = MRT_SHADER_RAYTRACING;
+    double paths_per_second = 0.0;  // measured on the scene's latest launch that handed out work
     int64_t opt_traversal = 0;  // 0 auto, 1 per-lane, 2 wave-synchronous over the tree, 3 over the leaf list, 4 candidates
     const DNodeRec* dev_node_recs = nullptr;
     const DNodeRec* dev_leaf_recs = nullptr;
@@ -2309,6 +2311,24 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     rp.seed = seed, rp.first_sample = first_sample;
     rp.steps = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(sc->opt_steps, 64));
     uint32_t n_slots = (uint32_t)std::min<unsigned long long>(sc->pool_slots, (rp.n_work + BLOCK - 1) / BLOCK * BLOCK);
+    // Claim size. Two pulls: small claims keep the waves finishing together (only a wave's own lanes
+    // start the items it holds, so with 512-item claims a small render is in effect partitioned
+    // statically and waits for its slowest waves), but every claim is an atomic on ONE counter, which
+    // the memory system serves at some tens of millions per second. So the claim is what keeps the
+    // claim rate near 16 M/s at the throughput the scene has shown on its latest launch, between one
+    // wave's worth and WORK_CHUNK. Before a scene's first launch: an eighth of a wave's share of the
+    // render (corrected after that launch).
+    auto claim_size = [&](double paths_per_second) {
+        unsigned long long c = (unsigned long long)(paths_per_second / 16.0e6);
+        c = (c + 63ull) & ~63ull;
+        return (uint32_t)(c < 64 ? 64 : (c > WORK_CHUNK ? WORK_CHUNK : c));
+    };
+    if (sc->paths_per_second > 0.0) {
+        rp.chunk = claim_size(sc->paths_per_second);
+    } else {
+        const unsigned long long per_wave = rp.n_work / (8ull * (n_slots / 64u) + 1ull);
+        rp.chunk = per_wave >= WORK_CHUNK ? WORK_CHUNK : (per_wave <= 64 ? 64u : (uint32_t)(per_wave & ~63ull));
+    }
     const int trav = traversal_mode(sc);
     SceneView view = view_for(sc, trav);
     view.trace_zero_throughput = (int32_t)sc->opt_trace_zero;
@@ -2376,6 +2396,7 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     double kernel_ms = 0.0;
     uint64_t launches = 0;
     uint32_t active = n_slots;
+    unsigned long long handed_before = 0;
     for (;;) {
         HIP_TRY(hipMemsetAsync(&sc->counters->live, 0, sizeof(unsigned int) * 2 + sizeof(unsigned long long), stream));
         rp.n_slots = active;
@@ -2398,6 +2419,15 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
         HIP_TRY(hipEventElapsedTime(&ms, ek0, ek1));
         kernel_ms += ms;
         launches++;
+        {
+            // throughput of this launch, for the claim size of the next one (and of the next render)
+            const unsigned long long handed = std::min<unsigned long long>(host.work_next, rp.n_work);
+            if (handed > handed_before && ms > 0.05f) {
+                sc->paths_per_second = (double)(handed - handed_before) / ((double)ms * 1e-3);
+                rp.chunk = claim_size(sc->paths_per_second);
+            }
+            handed_before = handed;
+        }
         bool work_left = host.work_next < rp.n_work || host.held > 0;
         if (!work_left && host.live == 0) break;
         if (!work_left && sc->opt_compact && host.live * 4ull < (unsigned long long)active * 3ull && active > BLOCK) {
