@@ -2419,6 +2419,11 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
         HIP_TRY(hipEventElapsedTime(&ms, ek0, ek1));
         kernel_ms += ms;
         launches++;
+#ifdef MRT_STAMPS
+        std::fprintf(stderr, "[stamps] launch %llu: %.2f ms, %u slots, claim %u, %u live after it, work handed out %llu of %llu\n",
+                     (unsigned long long)launches, ms, active, rp.chunk, host.live,
+                     (unsigned long long)std::min<unsigned long long>(host.work_next, rp.n_work), (unsigned long long)rp.n_work);
+#endif
         {
             // throughput of this launch, for the claim size of the next one (and of the next render)
             const unsigned long long handed = std::min<unsigned long long>(host.work_next, rp.n_work);
