@@ -1968,7 +1968,9 @@ __global__ void __launch_bounds__(BLOCK) k_single_bounce(SceneView sv, RenderPar
     uint32_t rays = live ? 1u : 0u;
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     Rng g0(key, 0);
-    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g0, live, h, st) : (live && nearest_hit_lane<FEAT>(sv, ray, g0, h, st));
+    CandLds cand_bits{nullptr, nullptr};
+    if constexpr (!WAVE && (FEAT & FEAT_OCTREE) == 0) cand_bits = candidate_lds(sv);
+    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g0, live, h, st) : (live && nearest_hit_lane<FEAT>(sv, ray, g0, h, st, cand_bits));
     F3 color{0.f, 0.f, 0.f};
     if constexpr (MODE == MRT_SHADER_DIFFUSE) {
         if (live) color = diffuse_stage<FEAT>(sv, ray, h, hit);
@@ -1991,7 +1993,7 @@ __global__ void __launch_bounds__(BLOCK) k_single_bounce(SceneView sv, RenderPar
             if (hit) object_generate<LF>(lights + i, pos_w, h.t, gi, rng_f64(gi, MRT_DIM_LIGHT_A), rng_f64(gi, MRT_DIM_LIGHT_B), ai);
             HitD h2{0.0, -1, 0, {0.0, 0.0, 0.0}};
             bool hit2 = WAVE ? nearest_hit_wave<FEAT>(sv, ai.to_area, gi, hit, h2, st)
-                             : (hit && nearest_hit_lane<FEAT>(sv, ai.to_area, gi, h2, st));
+                             : (hit && nearest_hit_lane<FEAT>(sv, ai.to_area, gi, h2, st, cand_bits));
             if (hit) rays++;
             if (hit && hit2) {
                 const DObjRec* ob2 = sv.objects + h2.obj;
