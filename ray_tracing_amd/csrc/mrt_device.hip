@@ -438,8 +438,16 @@ __device__ __forceinline__ bool aabb_hit(D3 mn, D3 mx, const RayD& r, D3 inv_d, 
 // the smallest parent that also contains the new cell: one or two levels up for most steps
 // instead of the whole depth from the root.
 constexpr int OCT_ANC_LEVELS = 16;
+// The per-lane LDS arrays of this file (octree ancestor cache, candidate-search bits and stack) live
+// in the workgroup's dynamic LDS, laid out [entry][thread], so that kernels can differ in workgroup
+// size; the two users never meet in one kernel (see lds_bytes), both start at offset 0.
+__device__ __forceinline__ uint32_t* dynamic_lds() {
+    extern __shared__ uint32_t mrt_dynamic_lds[];
+    return mrt_dynamic_lds;
+}
 struct OctCursor {
-    uint32_t* anc;      // this lane's column of a [OCT_ANC_LEVELS][BLOCK] array
+    uint32_t* anc;      // this lane's column of a [OCT_ANC_LEVELS][threads per workgroup] array
+    uint32_t stride;    // threads per workgroup
     int32_t x, y, z;    // cell of the previous lookup
     uint32_t leaf_exp;  // size exponent of the node it returned
     bool valid;
@@ -455,14 +463,14 @@ __device__ __forceinline__ DOctNode oct_chunk_near(const DOctNode* nodes, uint32
         if (s <= world_log2) {
             const uint32_t cs = s - 1;
             const uint32_t ci = ((((uint32_t)x >> cs) & 1u) << 2) | ((((uint32_t)y >> cs) & 1u) << 1) | (((uint32_t)z >> cs) & 1u);
-            n = nodes[c.anc[s * BLOCK] + ci];
+            n = nodes[c.anc[s * c.stride] + ci];
             from_root = false;
         }
     }
     if (from_root) n = nodes[root];
     while ((n.kind_size & 0xFF) == MRT_OCT_PARENT) {
         const uint32_t s = n.kind_size >> 8;
-        c.anc[s * BLOCK] = (uint32_t)n.link;
+        c.anc[s * c.stride] = (uint32_t)n.link;
         const uint32_t cs = s - 1;
         const uint32_t ci = ((((uint32_t)x >> cs) & 1u) << 2) | ((((uint32_t)y >> cs) & 1u) << 1) | (((uint32_t)z >> cs) & 1u);
         n = nodes[(uint32_t)n.link + ci];
@@ -632,8 +640,8 @@ template <bool VOL>
 __device__ bool oct_trace_ray(const DOctNode* nodes, const mrt_voxel* voxels, const DOctree& oc, D3 o, D3 d, const Rng& g,
                               uint32_t& entry, D3& hit_pos, int& code, int& voxel) {
     const double ws = (double)(1u << oc.world_log2);
-    __shared__ uint32_t oct_anc[OCT_ANC_LEVELS * BLOCK];
-    OctCursor cursor{oct_anc + threadIdx.x, 0, 0, 0, 0, false};
+    // (the workgroup's dynamic LDS: kernels with octree code are launched with lds_bytes() of it)
+    OctCursor cursor{dynamic_lds() + threadIdx.x, blockDim.x, 0, 0, 0, 0, false};
     if (o.x >= 0.0 && o.x <= ws && o.y >= 0.0 && o.y <= ws && o.z >= 0.0 && o.z <= ws) {
         return oct_ray_iteration<VOL>(nodes, voxels, oc, f64_as_i32(o.x), f64_as_i32(o.y), f64_as_i32(o.z), o, d, 1 /* unit_x */,
                                       g, entry, hit_pos, code, voxel, cursor);
@@ -877,6 +885,7 @@ __device__ __forceinline__ bool line_meets_child(const DCand4* nd, int k, bool m
 struct CandLds {
     LDS_AS uint32_t* bits;
     LDS_AS uint16_t* stack;
+    uint32_t stride;  // threads per workgroup
 };
 // Candidate search for large trees (host side: build_candidate_tree). Phase 1 walks the spatial
 // tree and marks every leaf whose tight box the ray's line meets, together with the leaf's
@@ -907,7 +916,7 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
                 if (child >= 0) {
                     // descend into the last child that was hit; the others wait on the stack
                     // (the host has checked that CAND_STACK entries are enough for this tree)
-                    if (next >= 0) lds.stack[sp++ * BLOCK] = (uint16_t)next;
+                    if (next >= 0) lds.stack[sp++ * lds.stride] = (uint16_t)next;
                     next = child;
                     continue;
                 }
@@ -919,7 +928,7 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (n4[e] >= 0) {
-                            (void)__hip_atomic_fetch_or(bits + (n4[e] >> 5) * BLOCK, 1u << (n4[e] & 31), __ATOMIC_RELAXED,
+                            (void)__hip_atomic_fetch_or(bits + (n4[e] >> 5) * lds.stride, 1u << (n4[e] & 31), __ATOMIC_RELAXED,
                                                         __HIP_MEMORY_SCOPE_WORKGROUP);
                             touched |= 1u << (n4[e] >> 5);
                         }
@@ -927,7 +936,7 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
             }
             if (next < 0) {
                 if (sp == 0) break;
-                next = lds.stack[--sp * BLOCK];
+                next = lds.stack[--sp * lds.stride];
             }
             node = next;
         }
@@ -944,8 +953,8 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
             if (touched == 0) return -1;
             wd = __ffs((int)touched) - 1;
             touched &= touched - 1;
-            m = bits[wd * BLOCK];
-            bits[wd * BLOCK] = 0;
+            m = bits[wd * lds.stride];
+            bits[wd * lds.stride] = 0;
         }
         const int idx = wd * 32 + __ffs((int)m) - 1;
         m &= m - 1;
@@ -974,7 +983,7 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
 }
 template <int FEAT>
 __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng& g, HitD& out, Stamps& st,
-                                 CandLds lds = CandLds{nullptr, nullptr}) {
+                                 CandLds lds = CandLds{nullptr, nullptr, 0}) {
     // (a zero or non-finite direction component makes slab bounds undefined: those rays take the walk)
     const double dmin = fmin(fabs(ray.d.x), fmin(fabs(ray.d.y), fabs(ray.d.z)));
     const double dmax = fmax(fabs(ray.d.x), fmax(fabs(ray.d.y), fabs(ray.d.z)));
@@ -1747,16 +1756,29 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
 // ============================================================== kernels
 // This lane's columns of the workgroup's candidate-search arrays (nearest_hit_candidates), bits cleared.
 __device__ __forceinline__ CandLds candidate_lds(const SceneView& sv) {
-    __shared__ uint32_t cand_words[CAND_WORDS * BLOCK];
-    __shared__ uint16_t cand_stack[CAND_STACK * BLOCK];
-    CandLds lds{(LDS_AS uint32_t*)cand_words + threadIdx.x, (LDS_AS uint16_t*)cand_stack + threadIdx.x};
-    for (int w = 0; w < sv.n_cand_words; ++w) lds.bits[w * BLOCK] = 0;
+    const uint32_t tpb = blockDim.x;
+    uint32_t* base = dynamic_lds();
+    CandLds lds{(LDS_AS uint32_t*)base + threadIdx.x, (LDS_AS uint16_t*)(base + CAND_WORDS * tpb) + threadIdx.x, tpb};
+    for (int w = 0; w < sv.n_cand_words; ++w) lds.bits[w * tpb] = 0;
     return lds;
 }
 // Waves per SIMD the segment kernel is compiled for (512 / waves registers per lane). Measured:
 // three waves hide the scene-record and pool latencies best as long as the kernel fits 168
 // registers without heavy spilling; the wave-synchronous kernels of the large feature sets
 // (specular materials, image / procedural textures) run faster with two.
+// Threads per workgroup of the segment kernel: single waves for the wave-synchronous kernels (nothing
+// is shared between the waves of a workgroup, and a wave's slot is free again the moment it ends:
+// +4 % on Cornell smoke, +8 % on the voxel city over 256), 256 for the per-lane kernels (measured
+// better with the candidate search's LDS traffic).
+constexpr int seg_block(bool wave) { return wave ? 64 : 256; }
+// Dynamic LDS a kernel of `threads` threads needs: the octree ancestor cache where octree code
+// exists, else the candidate-search arrays in the per-lane kernels (trees with octrees do not use
+// the candidate search).
+constexpr size_t lds_bytes(bool wave, int feat, int threads) {
+    if (feat & FEAT_OCTREE) return sizeof(uint32_t) * OCT_ANC_LEVELS * (size_t)threads;
+    if (!wave) return (sizeof(uint32_t) * CAND_WORDS + sizeof(uint16_t) * CAND_STACK) * (size_t)threads;
+    return 0;
+}
 constexpr int seg_waves(bool wave, int feat) {
     return (wave && (feat & (FEAT_SPECULAR | FEAT_TEXTURE)) != 0) ? 2 : 3;
 }
@@ -1769,9 +1791,9 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 // One launch = up to `steps` segments for every slot of the pool.
 template <bool WAVE, int FEAT>
-__global__ void __launch_bounds__(BLOCK, seg_waves(WAVE, FEAT)) k_segments(SceneView sv, Pool pool, RenderParams rp, Counters* ctr,
-                                                                     unsigned long long* wave_chunks) {
-    const uint32_t slot = blockIdx.x * BLOCK + threadIdx.x;
+__global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segments(SceneView sv, Pool pool, RenderParams rp,
+                                                                               Counters* ctr, unsigned long long* wave_chunks) {
+    const uint32_t slot = blockIdx.x * seg_block(WAVE) + threadIdx.x;
     const bool in_range = slot < rp.n_slots;
     int32_t seg = -1;
     RayD ray{{0, 0, 0}, {0, 0, 1}, 0};
@@ -1799,7 +1821,7 @@ __global__ void __launch_bounds__(BLOCK, seg_waves(WAVE, FEAT)) k_segments(Scene
     chunk_end = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(chunk_end >> 32)) << 32) |
                 __builtin_amdgcn_readfirstlane((uint32_t)chunk_end);
     bool dry = false;  // the global counter has run past the end of the work
-    CandLds cand_bits{nullptr, nullptr};
+    CandLds cand_bits{nullptr, nullptr, 0};
     // (kernels with octree code keep their LDS for the octree walk's ancestor cache)
     if constexpr (!WAVE && (FEAT & FEAT_OCTREE) == 0) cand_bits = candidate_lds(sv);
     Stamps st{};
@@ -1968,7 +1990,7 @@ __global__ void __launch_bounds__(BLOCK) k_single_bounce(SceneView sv, RenderPar
     uint32_t rays = live ? 1u : 0u;
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     Rng g0(key, 0);
-    CandLds cand_bits{nullptr, nullptr};
+    CandLds cand_bits{nullptr, nullptr, 0};
     if constexpr (!WAVE && (FEAT & FEAT_OCTREE) == 0) cand_bits = candidate_lds(sv);
     bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g0, live, h, st) : (live && nearest_hit_lane<FEAT>(sv, ray, g0, h, st, cand_bits));
     F3 color{0.f, 0.f, 0.f};
@@ -2071,7 +2093,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_rays(SceneView sv, const double
     Rng g{path_key(seed, (uint64_t)i, 0), 0};
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     Stamps st{};
-    CandLds cand_bits{nullptr, nullptr};
+    CandLds cand_bits{nullptr, nullptr, 0};
     // (kernels with octree code keep their LDS for the octree walk's ancestor cache)
     if constexpr (!WAVE && (FEAT & FEAT_OCTREE) == 0) cand_bits = candidate_lds(sv);
     bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g, live, h, st) : (live && nearest_hit_lane<FEAT>(sv, ray, g, h, st, cand_bits));
@@ -2362,13 +2384,13 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
             dispatch_feat(sc->features, SingleBounceFeats{}, [&](auto feat) {
                 constexpr int FT = decltype(feat)::value;
                 if (wave_sync && light_map)
-                    hipLaunchKernelGGL((k_single_bounce<true, FT, MRT_SHADER_LIGHT_MAP>), grid, block, 0, stream, view, rp, w0, w1, sc->counters);
+                    hipLaunchKernelGGL((k_single_bounce<true, FT, MRT_SHADER_LIGHT_MAP>), grid, block, lds_bytes(true, FT, BLOCK), stream, view, rp, w0, w1, sc->counters);
                 else if (wave_sync)
-                    hipLaunchKernelGGL((k_single_bounce<true, FT, MRT_SHADER_DIFFUSE>), grid, block, 0, stream, view, rp, w0, w1, sc->counters);
+                    hipLaunchKernelGGL((k_single_bounce<true, FT, MRT_SHADER_DIFFUSE>), grid, block, lds_bytes(true, FT, BLOCK), stream, view, rp, w0, w1, sc->counters);
                 else if (light_map)
-                    hipLaunchKernelGGL((k_single_bounce<false, FT, MRT_SHADER_LIGHT_MAP>), grid, block, 0, stream, view, rp, w0, w1, sc->counters);
+                    hipLaunchKernelGGL((k_single_bounce<false, FT, MRT_SHADER_LIGHT_MAP>), grid, block, lds_bytes(false, FT, BLOCK), stream, view, rp, w0, w1, sc->counters);
                 else
-                    hipLaunchKernelGGL((k_single_bounce<false, FT, MRT_SHADER_DIFFUSE>), grid, block, 0, stream, view, rp, w0, w1, sc->counters);
+                    hipLaunchKernelGGL((k_single_bounce<false, FT, MRT_SHADER_DIFFUSE>), grid, block, lds_bytes(false, FT, BLOCK), stream, view, rp, w0, w1, sc->counters);
             });
             HIP_TRY(hipGetLastError());
         }
@@ -2404,13 +2426,15 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
         rp.n_slots = active;
         HIP_TRY(hipEventRecord(ek0, stream));
         {
-            const dim3 grid((active + BLOCK - 1) / BLOCK), block(BLOCK);
+            // (`active` is a multiple of BLOCK, which both workgroup sizes divide)
             dispatch_feat(sc->features, KernelFeats{}, [&](auto feat) {
                 constexpr int FT = decltype(feat)::value;
                 if (wave_sync)
-                    hipLaunchKernelGGL((k_segments<true, FT>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters, sc->wave_chunks);
+                    hipLaunchKernelGGL((k_segments<true, FT>), dim3(active / seg_block(true)), dim3(seg_block(true)),
+                                       lds_bytes(true, FT, seg_block(true)), stream, view, sc->pool[cur], rp, sc->counters, sc->wave_chunks);
                 else
-                    hipLaunchKernelGGL((k_segments<false, FT>), grid, block, 0, stream, view, sc->pool[cur], rp, sc->counters, sc->wave_chunks);
+                    hipLaunchKernelGGL((k_segments<false, FT>), dim3(active / seg_block(false)), dim3(seg_block(false)),
+                                       lds_bytes(false, FT, seg_block(false)), stream, view, sc->pool[cur], rp, sc->counters, sc->wave_chunks);
             });
         }
         HIP_TRY(hipGetLastError());
@@ -2639,9 +2663,9 @@ int mrt_trace_rays(mrt_scene* scene, const double* rays, size_t n, uint64_t seed
         dispatch_feat(scene->features, KernelFeats{}, [&](auto feat) {
             constexpr int FT = decltype(feat)::value;
             if (ws)
-                hipLaunchKernelGGL((k_trace_rays<true, FT>), grid, block, 0, 0, view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
+                hipLaunchKernelGGL((k_trace_rays<true, FT>), grid, block, lds_bytes(true, FT, BLOCK), 0, view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
             else
-                hipLaunchKernelGGL((k_trace_rays<false, FT>), grid, block, 0, 0, view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
+                hipLaunchKernelGGL((k_trace_rays<false, FT>), grid, block, lds_bytes(false, FT, BLOCK), 0, view, drays, (uint32_t)n, seed, did, dt, dn, dp, dff);
         });
     }
     HIP_TRY(hipGetLastError());
