@@ -390,7 +390,9 @@ enum mrt_shader { MRT_SHADER_RAYTRACING = 0, MRT_SHADER_DIFFUSE = 1, MRT_SHADER_
 /* Tuning knobs (performance only; results change at most in the order of the
  * f32 accumulation adds, except "trace_zero_throughput"):
  *   "pool_slots"             path slots in flight (default 2^21)
- *   "segments_per_launch"    1..64 segments per kernel launch (default 32)
+ *   "segments_per_launch"    1..1024 segments per kernel launch (default 1024:
+ *                            a launch runs until the work is handed out and most paths
+ *                            have ended; smaller values bound the time of one launch)
  *   "compaction"             0/1 pack live paths in the drain phase (default 1)
  *   "traversal"              0 auto, 1 per-lane tree walk, 2 wave-synchronous
  *                            tree walk, 3 wave-synchronous walk over the leaf list,
