@@ -390,7 +390,7 @@ enum mrt_shader { MRT_SHADER_RAYTRACING = 0, MRT_SHADER_DIFFUSE = 1, MRT_SHADER_
 /* Tuning knobs (performance only; results change at most in the order of the
  * f32 accumulation adds, except "trace_zero_throughput"):
  *   "pool_slots"             path slots in flight (default 2^21)
- *   "segments_per_launch"    1..1024 segments per kernel launch (default 1024:
+ *   "segments_per_launch"    1..65536 segments per kernel launch (default 4096:
  *                            a launch runs until the work is handed out and most paths
  *                            have ended; smaller values bound the time of one launch)
  *   "compaction"             0/1 pack live paths in the drain phase (default 1)

@@ -2178,7 +2178,7 @@ struct mrt_scene {
     uint32_t pool_slots = 0;
     // options
     int64_t opt_pool_slots = 1 << 21;
-    int64_t opt_steps = 1024;
+    int64_t opt_steps = 4096;
     int64_t opt_trace_zero = 0;
     int64_t opt_compact = 1;
     int64_t opt_shader = MRT_SHADER_RAYTRACING;
@@ -2333,7 +2333,7 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     rp.inv_npix_strip = 1.0 / (double)rp.npix_strip;
     rp.inv_strip_w = 1.0 / (double)strip_w;
     rp.seed = seed, rp.first_sample = first_sample;
-    rp.steps = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(sc->opt_steps, 1024));
+    rp.steps = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(sc->opt_steps, 65536));
     uint32_t n_slots = (uint32_t)std::min<unsigned long long>(sc->pool_slots, (rp.n_work + BLOCK - 1) / BLOCK * BLOCK);
     // Claim size. Two pulls: small claims keep the waves finishing together (only a wave's own lanes
     // start the items it holds, so with 512-item claims a small render is in effect partitioned
@@ -2591,7 +2591,7 @@ int mrt_scene_set_option(mrt_scene* scene, const char* name, int64_t value) {
         if (value < BLOCK) return set_error(MRT_ERR_INVALID_ARGUMENT, "pool_slots too small");
         scene->opt_pool_slots = value;
     } else if (n == "segments_per_launch") {
-        if (value < 1 || value > 1024) return set_error(MRT_ERR_INVALID_ARGUMENT, "segments_per_launch must be 1..1024");
+        if (value < 1 || value > 65536) return set_error(MRT_ERR_INVALID_ARGUMENT, "segments_per_launch must be 1..65536");
         scene->opt_steps = value;
     } else if (n == "trace_zero_throughput") {
         scene->opt_trace_zero = value ? 1 : 0;

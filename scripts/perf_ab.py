@@ -10,7 +10,7 @@ cfgs = [eval("dict(" + a + ")") for a in sys.argv[3:]]
 W, H = (3840, 2160) if name == "Voxel City" else (1920, 1080)
 rt = RayTracer(scene_by_name(name), device=0, seed=0)
 accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
-defaults = dict(segments_per_launch=1024, pool_slots=1 << 21, traversal=0)
+defaults = dict(segments_per_launch=4096, pool_slots=1 << 21, traversal=0)
 rt.render_device(accum.data_ptr(), W, H, 2)
 for rep in range(3):
     for cfg in cfgs:
