@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-B_SEG = 220.0   # algorithmic HBM bytes per path segment (ray + hit + state streams)
+B_SEG = 220.0   # algorithmic HBM bytes per path segment: ray 48 + id 4 read, hit 12 written; ray + hit + state 80 read,
+                # next ray + state 68 written; 8 for the compaction index
 B_PATH = 24.0   # algorithmic HBM bytes per path (accumulation read-modify-write)
 HBM_PEAK_GBS = 8000.0
 

@@ -250,7 +250,7 @@ def test_empty_world_renders_background():
 
 
 def test_full_size_properties_1080p(worlds):
-    """BASELINE config size (1920x1080): properties that need no full-size CPU render."""
+    """The benchmark's image size (1920x1080): properties that need no full-size CPU render."""
     info, rt, ow = worlds("Cornell Smoke", seed=3)
     W, H = 1920, 1080
     a, sa = gpu_render(rt, W, H, 4, first=0)

@@ -415,7 +415,7 @@ def test_vox_fixture_and_city_tree(lib):
     c, col = b.voxels()
     assert c.max(axis=0).tolist() == [63, 235, 63]           # load.rs:116-122: y <- vox z, z <- flipped vox y
     grid = city_grid(b)
-    assert grid.world_size() == 512
+    assert grid.world_size() == 512                          # 512^3 city world (fast_oct_tree.rs:818-883)
     vg = grid.linearise()
     assert vg.nodes[vg.root]["size"] == 9
     # literal reference construction of the same voxels (roads in IterBox order, then the building)

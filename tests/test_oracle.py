@@ -115,7 +115,7 @@ def test_sample_ranges_add_up():
 
 
 def test_cornell_quirks():
-    """the green wall (x=555), ceiling and back wall have outward normals and stay black;
+    """cornell_smoke.rs builds these rects with flip = false: the green wall (x=555), ceiling and back wall have outward normals and stay black;
     the light is visible; camera rays through the smoke sphere may scatter."""
     ow = oracle_ffi.OracleWorld(scenarios.cornell_smoke())
     img, _ = ow.render(64, 64, 64, seed=1, threads=8)
