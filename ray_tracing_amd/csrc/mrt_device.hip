@@ -70,7 +70,7 @@ struct Pool {
 // Work items (pixel-samples) are handed out in chunks: a wave takes WORK_CHUNK consecutive items
 // from the global counter with one atomic and serves its lanes from that range; what is left of
 // the range when a launch ends is kept per wave ([next, end) pairs) for the next launch.
-constexpr uint32_t WORK_CHUNK = 512;
+constexpr uint32_t WORK_CHUNK = 1024;
 constexpr int BLOCK = 256;  // threads per workgroup of every kernel here
 
 enum : int { ST_REGEN = 0, ST_TRAVERSE, ST_LEAF, ST_SURFACE, ST_LAMBERT_GEN, ST_LIGHT_VALUE, ST_SHADE, ST_ACCUM, ST_TOTAL, ST_MEDIUM_TAIL, ST_CLAIM, ST_GEN_COS, ST_GEN_LIGHT, ST_GEN_SKY, ST_ISOTROPIC, ST_CAND_SEARCH, ST_COUNT };
@@ -2339,11 +2339,11 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     // start the items it holds, so with 512-item claims a small render is in effect partitioned
     // statically and waits for its slowest waves), but every claim is an atomic on ONE counter, which
     // the memory system serves at some tens of millions per second. So the claim is what keeps the
-    // claim rate near 16 M/s at the throughput the scene has shown on its latest launch, between one
+    // claim rate near 8 M/s at the throughput the scene has shown on its latest launch, between one
     // wave's worth and WORK_CHUNK. Before a scene's first launch: an eighth of a wave's share of the
     // render (corrected after that launch).
     auto claim_size = [&](double paths_per_second) {
-        unsigned long long c = (unsigned long long)(paths_per_second / 16.0e6);
+        unsigned long long c = (unsigned long long)(paths_per_second / 8.0e6);
         c = (c + 63ull) & ~63ull;
         return (uint32_t)(c < 64 ? 64 : (c > WORK_CHUNK ? WORK_CHUNK : c));
     };
