@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
-"""Benchmark: Cornell smoke 1920x1080 path tracing throughput (Mpaths/s) on N MI355X.
+"""Benchmark: path-tracing throughput (Mpaths/s) of the HIP path on N MI355X, one rank per GPU.
 
 One step = one full render of the frame at --spp samples per pixel through the C ABI
-(`mrt_render_accumulate_device`), accumulation buffer resident in HBM. With N > 1 GPUs each
-rank renders --spp samples with its own disjoint sample-index range (weak scaling: the joined
-image holds N x spp samples) and the ranks' buffers are summed by one all-reduce (RCCL) inside
-the timed region. Rank 0 prints one JSON line.
+(`mrt_render_accumulate_device`), accumulation buffer resident in HBM. Default workload: Cornell
+smoke 1920x1080 at 1024 spp.
+
+N > 1: samples are split across ranks by sample index and the ranks' buffers are summed by ONE
+all-reduce (RCCL through torch.distributed's "nccl" backend) inside the timed region.
+  weak scaling (default): every rank renders --spp samples, the joined image holds N x spp samples;
+  --strong:               --spp is the total, rank r renders its share of the sample indices
+                          (3840x2160 at 16384 spp over eight GPUs is `--strong --width 3840
+                          --height 2160 --spp 16384 --gpus 8`).
+Started without a launcher (`python bench.py --gpus N`, WORLD_SIZE unset) the parent process
+starts the N ranks itself as fresh child processes, before it touches torch or the GPU, and passes
+rank 0's JSON line through. Started under torch.distributed.run it is one of the ranks.
+`--backend gloo --dry` rehearses the rank plumbing on CPUs (no rendering, no GPU).
 """
 from __future__ import annotations
 
 import argparse
-import ctypes as C
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,13 +31,55 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-B_SEG = 220.0   # algorithmic HBM bytes per path segment: ray 48 + id 4 read, hit 12 written; ray + hit + state 80 read,
-                # next ray + state 68 written; 8 for the compaction index
+B_SEG = 220.0   # algorithmic HBM bytes per path segment of a queue-based wavefront tracer: ray 48 + id 4 read,
+                # hit 12 written; ray + hit + state 80 read, next ray + state 68 written; 8 for the compaction index
 B_PATH = 24.0   # algorithmic HBM bytes per path (accumulation read-modify-write)
 HBM_PEAK_GBS = 8000.0
+FP64_VECTOR_PEAK_TFLOPS = 78.6
 
 
-def cpu_baseline(info, width, height, spp, threads):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scene", default="Cornell Smoke", help="scenario name (ray_tracing_amd.scenarios) or 'Voxel City'")
+    ap.add_argument("--strong", action="store_true", help="--spp is the total over all ranks (strong scaling)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--dry", action="store_true", help="no rendering and no GPU: rank plumbing and all-reduce only")
+    ap.add_argument("--pool-slots", type=int, default=0)
+    ap.add_argument("--segments-per-launch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=64)
+    ap.add_argument("--post", action="store_true", help="also time bloom + to_image on the device-resident image")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args) -> int:
+    """Starts args.gpus fresh rank processes of this script (nothing in this process has touched
+    torch or the GPU) and passes rank 0's output through. Returns the worst exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+def cpu_baseline(info, width, height, spp, threads, label):
     """Times the CPU checker (a C++ port of the reference's CPU path) on a bounded sample."""
     from tests.oracle_ffi import OracleWorld
 
@@ -36,73 +89,134 @@ def cpu_baseline(info, width, height, spp, threads):
     dt = time.perf_counter() - t0
     return {"value": st.paths / dt / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
             "mrays_per_s": st.rays / dt / 1e6, "seconds": dt,
-            "sample": f"Cornell smoke {width}x{height} @ {spp} spp, {threads} threads over vertical strips "
+            "sample": f"{label} {width}x{height} @ {spp} spp, {threads} threads over vertical strips "
                       f"(threaded_render layout)"}
 
 
-def pmc_traffic(workload, launches_per_step):
-    """HBM bytes per segment-kernel launch from the committed rocprofv3 counter passes
-    (profiles/*_pmc_traffic.json, written by scripts/pmc_traffic.py), or None when no pass of this
-    workload with the same launch count per step is on file. Counters cannot be read from inside
-    the timed run, so the value is that of the profiled run of this same command."""
-    import glob
+def host_description():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"cpu_model": model, "nproc": os.cpu_count() or 1, "usable_cores": usable}
+
+
+def committed_profile(workload_key):
+    """Counter figures of the segment kernel from the committed rocprofv3 passes of this workload
+    (profiles/*_pmc_traffic.json, written by scripts/pmc_traffic.py from scripts/profile_bench.sh
+    runs of this same command; counters cannot be read inside the timed run). Newest file wins."""
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
         try:
             d = json.load(open(f))
-            line = d.get("bench_line_under_trace", {})
-            same = line.get("config", {}).get("workload") == workload
-            per_step = line.get("roofline", {}).get("launches", 0) / max(1, line.get("steps", 1))
-            if same and abs(per_step - launches_per_step) <= 1 and "hbm_bytes_per_launch" in d:
-                best = float(d["hbm_bytes_per_launch"])
         except (OSError, ValueError):
             continue
+        line = d.get("bench_line_under_trace", {})
+        if line.get("config", {}).get("profile_key") == workload_key or \
+                (workload_key.startswith("cornell_smoke 1920x1080 @ 1024") and
+                 str(line.get("config", {}).get("workload", "")).startswith("cornell_smoke 1920x1080 @ 1024")):
+            d["file"] = os.path.relpath(f, ROOT)
+            best = d
     return best
 
 
+def build_scene(name):
+    from ray_tracing_amd import scenarios
+    if name in ("Cornell Smoke", "cornell_smoke"):
+        return scenarios.cornell_smoke()
+    from tests.helpers import scene_by_name   # data fixtures (decoded .vox, earthmap) live under tests/golden
+    return scene_by_name(name)
+
+
+def post_leg(rt, accum, W, H, spp, repeats=5):
+    """bloom(accum / spp) and the 8-bit mapping on the device-resident image, HIP-event timed."""
+    import torch
+    out = torch.empty_like(accum)
+    rgb8 = torch.empty((H, W, 3), dtype=torch.uint8, device=accum.device)
+    stream = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for name, fn in (("bloom", lambda: rt.bloom_device(accum.data_ptr(), W, H, spp, out.data_ptr(), stream)),
+                     ("to_image", lambda: rt.to_image_device(out.data_ptr(), W, H, 1, rgb8.data_ptr(), stream))):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(repeats):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name + "_ms"] = e0.elapsed_time(e1) / repeats
+    img_bytes = 12.0 * W * H
+    # bloom: select 1 read + 2 writes; per level (sizes 1, 1/4, ...): down-sample, blur x, blur y (read + write each),
+    # up-add (2 reads + 1 write); tone map 2 reads + 1 write -> about 3 + 1.333 * (2 + 2 + 2 + 3) + 3 = 18 image passes
+    res["bloom_algorithmic_bytes"] = 18.0 * img_bytes
+    res["bloom_gbs"] = res["bloom_algorithmic_bytes"] / (res["bloom_ms"] * 1e-3) / 1e9
+    res["bloom_hbm_frac"] = res["bloom_gbs"] / HBM_PEAK_GBS
+    res["to_image_gbs"] = (img_bytes + 3.0 * W * H) / (res["to_image_ms"] * 1e-3) / 1e9
+    res["image"] = f"{W}x{H}"
+    return res
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=1024)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--pool-slots", type=int, default=0)
-    ap.add_argument("--segments-per-launch", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=64)
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
 
     import torch
     import torch.distributed as dist
 
-    from ray_tracing_amd import RayTracer, scenarios
-    from ray_tracing_amd.distributed import render_sharded
+    from ray_tracing_amd.distributed import render_sharded, sample_range
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world_size != args.gpus and world_size > 1:
+    if world_size != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_size}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    use_gpu = not args.dry
+    if use_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback); --dry rehearses the ranks on CPUs")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node")
+        torch.cuda.set_device(local_rank)
     if world_size > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl" and use_gpu:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
-    info = scenarios.cornell_smoke()
-    rt = RayTracer(info, device=local_rank, seed=0)
-    if args.pool_slots:
-        rt.world.set_option("pool_slots", args.pool_slots)
-    if args.segments_per_launch:
-        rt.world.set_option("segments_per_launch", args.segments_per_launch)
-    W, H, spp = args.width, args.height, args.spp
-    accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream()
+    W, H = args.width, args.height
+    total_spp = args.spp if args.strong else args.spp * world_size
+    my_first, my_spp = sample_range(total_spp, rank, world_size)
+    device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+    accum = torch.zeros((H, W, 3), dtype=torch.float32, device=device)
     totals = {"paths": 0, "rays": 0, "lq": 0, "kernel_ms": 0.0, "launches": 0}
 
+    rt = info = None
+    if use_gpu:
+        from ray_tracing_amd import RayTracer
+        info = build_scene(args.scene)
+        rt = RayTracer(info, device=local_rank, seed=0)
+        if args.pool_slots:
+            rt.world.set_option("pool_slots", args.pool_slots)
+        if args.segments_per_launch:
+            rt.world.set_option("segments_per_launch", args.segments_per_launch)
+        stream = torch.cuda.current_stream()
+
     def render(first, count):
+        if not use_gpu:
+            accum.add_(float(count))          # stands in for `count` samples of radiance 1
+            totals["paths"] += W * H * count
+            return
         st = rt.render_device(accum.data_ptr(), W, H, count, first_sample=first, stream=stream.cuda_stream)
         totals["paths"] += st.paths
         totals["rays"] += st.rays
@@ -112,13 +226,13 @@ def main():
 
     def step():
         accum.zero_()
-        # weak scaling: every rank renders `spp` samples, sample indices [rank*spp, (rank+1)*spp)
-        render_sharded(render, lambda: dist.all_reduce(accum), spp * world_size, rank, world_size)
+        render_sharded(render, lambda: dist.all_reduce(accum), total_spp, rank, world_size)
 
     def sync():
         if world_size > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if use_gpu:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -128,27 +242,31 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
     sync()
     elapsed = time.perf_counter() - t0
     if world_size > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([totals["paths"], totals["rays"], totals["lq"]], dtype=torch.float64, device="cuda")
+        c = torch.tensor([totals["paths"], totals["rays"], totals["lq"]], dtype=torch.float64, device=device)
         dist.all_reduce(c)
         all_paths, all_rays, all_lq = (float(x) for x in c.tolist())
     else:
         all_paths, all_rays, all_lq = float(totals["paths"]), float(totals["rays"]), float(totals["lq"])
 
     if rank == 0:
-        mean = accum.mean().item() / (spp * world_size)
+        mean = accum.double().mean().item() / max(1, total_spp)
         kernel_s = totals["kernel_ms"] / 1e3
+        launches = max(1, totals["launches"])
         algo_bytes = B_SEG * totals["rays"] + B_PATH * totals["paths"]   # this rank's segment kernels
         achieved = algo_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
-        workload = f"cornell_smoke {W}x{H} @ {spp} spp per GPU, depth 50, seed 0"
+        scene_key = args.scene.lower().replace(",", "").replace(" ", "_")
+        per_gpu = f"{my_spp} spp per GPU" if not args.strong else f"{total_spp} spp split over {world_size} GPUs"
+        workload = f"{scene_key} {W}x{H} @ {per_gpu}, depth 50, seed 0"
+        profile_key = f"{scene_key} {W}x{H} @ {my_spp} spp per rank"
         out = {
-            "metric": "Mpaths/s, Cornell smoke 1920x1080",
+            "metric": f"Mpaths/s, {args.scene} {W}x{H}" if scene_key != "cornell_smoke" or (W, H) != (1920, 1080)
+                      else "Mpaths/s, Cornell smoke 1920x1080",
             "value": all_paths / elapsed / 1e6,
             "unit": "Mpaths/s",
             "n_gpus": world_size,
@@ -156,33 +274,72 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": workload,
-                       "parallelism": f"spp-split x{world_size} + one all-reduce of the f32 accumulation buffer"},
+            "config": {"workload": workload, "profile_key": profile_key,
+                       "parallelism": f"spp-split x{world_size} + one all-reduce of the f32 accumulation buffer "
+                                      f"({args.backend if world_size > 1 else 'single rank'})"},
             "mrays_per_s": all_rays / elapsed / 1e6,
             "light_queries_per_s_M": all_lq / elapsed / 1e6,
             "segments_per_path": all_rays / all_paths if all_paths else 0.0,
             "mean_radiance": mean,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(workload, totals["launches"] / max(1, args.steps)),
-                         "kernel": "k_segments", "avg_launch_ms": totals["kernel_ms"] / max(1, totals["launches"]),
-                         "launches": totals["launches"],
-                         "algorithmic_bytes_per_launch": algo_bytes / max(1, totals["launches"])},
         }
-        if world_size == 1 and not args.no_cpu_baseline:
-            threads = min(16, os.cpu_count() or 1)
-            cb = cpu_baseline(info, W, H, args.cpu_spp, threads)
-            # the reference's own layout: eight worker threads over eight vertical strips (ray_tracer.rs:496-497)
-            ref8 = cpu_baseline(info, W, H, max(1, args.cpu_spp // 8), 8)
-            cb["reference_layout_8_threads"] = {k: ref8[k] for k in ("value", "unit", "cores", "seconds", "sample")}
-            out["cpu_baseline"] = cb
-            out["gpu_over_cpu"] = out["value"] / cb["value"] if cb["value"] else None
+        if args.dry:
+            out["dry"] = True
+            out["config"]["workload"] = "dry run: no rendering, rank plumbing and all-reduce only"
+        else:
+            avg_launch_s = kernel_s / launches
+            roof = {
+                # What limits the kernel is vector-ALU issue under divergence (see the counter figures below),
+                # not HBM: path state stays in registers between the segments of a launch. `achieved` / `frac`
+                # keep the survey's ALGORITHMIC-bytes accounting (220 B per segment + 24 B per path, the traffic
+                # of a queue-based wavefront tracer) over the kernel's HIP-event time; `measured_hbm_frac` is
+                # what the kernel really moves.
+                "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "frac_is": "algorithmic bytes / kernel time / HBM peak",
+                "traffic": None, "kernel": "k_segments", "avg_launch_ms": avg_launch_s * 1e3,
+                "launches": totals["launches"], "algorithmic_bytes_per_launch": algo_bytes / launches,
+            }
+            prof = committed_profile(profile_key)
+            if prof:
+                roof["counters_from"] = prof["file"]
+                prof_launches_per_step = prof.get("bench_line_under_trace", {}).get("roofline", {}).get("launches", 0) / \
+                    max(1, prof.get("bench_line_under_trace", {}).get("steps", 1))
+                same_launches = abs(prof_launches_per_step - totals["launches"] / max(1, args.steps)) <= 1
+                if "hbm_bytes_per_launch" in prof and same_launches:
+                    roof["traffic"] = float(prof["hbm_bytes_per_launch"])
+                    roof["measured_hbm_frac"] = roof["traffic"] / avg_launch_s / (HBM_PEAK_GBS * 1e9)
+                sq = prof.get("sq", {})
+                if sq:
+                    roof["lane_utilisation"] = sq.get("lane_utilisation")
+                    roof["valu_active_per_wave_cycle"] = sq.get("valu_active_per_wave_cycle")
+                    roof["valu_issue_busy"] = sq.get("valu_issue_busy")
+                mix = prof.get("f64_mix", {})
+                if mix.get("f64_flops_per_segment"):
+                    roof["fp64_flops_per_segment"] = mix["f64_flops_per_segment"]
+                    roof["fp64_flops_source"] = mix.get("source")
+                    roof["fp64_flops_frac"] = mix["f64_flops_per_segment"] * totals["rays"] / kernel_s / \
+                        (FP64_VECTOR_PEAK_TFLOPS * 1e12)
+            out["roofline"] = roof
+            if args.post:
+                out["post"] = post_leg(rt, accum, W, H, total_spp)
+            if world_size == 1 and not args.no_cpu_baseline:
+                host = host_description()
+                threads = min(16, host["usable_cores"])
+                label = args.scene
+                cb = cpu_baseline(info, W, H, args.cpu_spp, threads, label)
+                # the reference's own layout: eight worker threads over eight vertical strips (ray_tracer.rs:496-497)
+                ref8 = cpu_baseline(info, W, H, max(1, args.cpu_spp // 8), 8, label)
+                cb["reference_layout_8_threads"] = {k: ref8[k] for k in ("value", "unit", "cores", "seconds", "sample")}
+                cb["host"] = host
+                cb["build"] = "g++ -O3 without -march=native (the checker is built off the GPU box)"
+                out["cpu_baseline"] = cb
+                out["gpu_over_cpu"] = out["value"] / cb["value"] if cb["value"] else None
         print(json.dumps(out), flush=True)
     if world_size > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -331,11 +331,18 @@ int mrt_render_accumulate(mrt_scene* scene, float* accum_rgb, uint32_t width, ui
  * reference's (ray_tracer.rs:479-535 drives all its workers from one process).
  * Handle i renders the i-th share of the sample range
  * [first_sample_index, first_sample_index + spp) on its own device, concurrently
- * with the others; the shares are then added into `accum_rgb` (HOST memory) in
- * handle order, so the result is the one-handle result up to the order of the
- * f32 additions. `stats`: sums of the counters, the longest kernel time, the
- * wall time of the call. Multi-process hosts split the samples the same way and
- * all-reduce the buffers instead (one rank per GPU). */
+ * with the others, into an image that stays resident on that device between
+ * calls (handles that share a device share its image). The strip of `accum_rgb`
+ * (HOST memory) is uploaded once, the per-device images are summed on the
+ * devices with one ncclAllReduce per device (RCCL, bound with dlopen at first
+ * use; a host-side sum of the downloaded strips replaces it when the library
+ * cannot be loaded), and the strip is downloaded once: the result is the
+ * one-handle result up to the order of the f32 additions. With the environment
+ * variable MRT_MULTI_FORCE_RCCL set, the collective also runs when all handles
+ * share one device (a world of one), and a failure of it is an error instead of
+ * a fall-back. `stats`: sums of the counters, the longest kernel time, the wall
+ * time of the call. Multi-process hosts split the samples the same way and
+ * all-reduce the buffers themselves (one rank per GPU). */
 int mrt_render_accumulate_multi(mrt_scene* const* scenes, uint32_t n_scenes, float* accum_rgb,
                                 uint32_t width, uint32_t height, uint32_t x0, uint32_t strip_w,
                                 uint32_t spp, uint64_t seed, uint64_t first_sample_index,
@@ -343,7 +350,11 @@ int mrt_render_accumulate_multi(mrt_scene* const* scenes, uint32_t n_scenes, flo
 
 /* Same, with `accum_rgb_device` resident on the scene's device (e.g. a torch
  * tensor's data pointer). `stream` is a hipStream_t (NULL = default stream);
- * the call returns after the work has completed on that stream. */
+ * the call returns after the work has completed on that stream.
+ * The buffer must be ordinary device memory of the scene's GPU (hipMalloc /
+ * a torch CUDA tensor): samples are added with hardware f32 atomics, which
+ * host-pinned, managed or fine-grained memory may silently drop; any other
+ * kind of pointer is rejected with MRT_ERR_INVALID_ARGUMENT. */
 int mrt_render_accumulate_device(mrt_scene* scene, float* accum_rgb_device, uint32_t width,
                                  uint32_t height, uint32_t x0, uint32_t strip_w, uint32_t spp,
                                  uint64_t seed, uint64_t first_sample_index, void* stream,

@@ -13,13 +13,18 @@
 // Every device function cites the reference lines it implements
 // (paths relative to cpu_rt/src/).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is bound with dlopen at first use
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -126,6 +131,7 @@ struct RenderParams {
     uint32_t n_slots;
     uint32_t steps;
     uint32_t chunk;  // work items a wave claims at a time
+    uint32_t all_claimed;  // the global counter had run past the end of the work before this launch
     double inv_npix_strip, inv_strip_w;  // reciprocals for the work-index decomposition
 };
 
@@ -1820,7 +1826,7 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
                  __builtin_amdgcn_readfirstlane((uint32_t)chunk_next);
     chunk_end = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(chunk_end >> 32)) << 32) |
                 __builtin_amdgcn_readfirstlane((uint32_t)chunk_end);
-    bool dry = false;  // the global counter has run past the end of the work
+    bool dry = rp.all_claimed != 0;  // the global counter has run past the end of the work
     CandLds cand_bits{nullptr, nullptr, 0};
     // (kernels with octree code keep their LDS for the octree walk's ancestor cache)
     if constexpr (!WAVE && (FEAT & FEAT_OCTREE) == 0) cand_bits = candidate_lds(sv);
@@ -2187,7 +2193,20 @@ struct mrt_scene {
     const DNodeRec* dev_node_recs = nullptr;
     const DNodeRec* dev_leaf_recs = nullptr;
     int features = 0;           // FEAT_* bits the scene needs
+    // per-scene call resources, created with the scene so that a render call creates nothing:
+    // events (whole call begin / end, segment kernel begin / end) and a pinned host copy of the counters
+    hipEvent_t events[4]{};
+    int n_events = 0;
+    Counters* host_counters = nullptr;
+    // accumulation image of mrt_render_accumulate_multi (resident between calls)
+    float* multi_accum = nullptr;
+    size_t multi_accum_floats = 0;
     std::mutex mu;
+    ~mrt_scene() {
+        for (int i = 0; i < n_events; ++i) (void)hipEventDestroy(events[i]);
+        if (host_counters) (void)hipHostFree(host_counters);
+        if (multi_accum) (void)hipFree(multi_accum);
+    }
 };
 
 // Feature sets the kernels are instantiated for, smallest first; the last one covers everything.
@@ -2308,6 +2327,13 @@ int ensure_pool(mrt_scene* sc) {
     return MRT_OK;
 }
 
+// Events and the pinned counter copy of a scene (created once, with the scene's device current).
+int create_call_resources(mrt_scene* sc) {
+    for (; sc->n_events < 4; ++sc->n_events) HIP_TRY(hipEventCreate(&sc->events[sc->n_events]));
+    if (!sc->host_counters) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sc->host_counters), sizeof(Counters), hipHostMallocDefault));
+    return MRT_OK;
+}
+
 // Render loop on `stream`; accum is device memory.
 int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t height, uint32_t x0, uint32_t strip_w,
                   uint32_t spp, uint64_t seed, uint64_t first_sample, hipStream_t stream, mrt_stats* stats) {
@@ -2317,24 +2343,48 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     if ((uint64_t)width * height > 0xFFFFFFFFull / 3) return set_error(MRT_ERR_INVALID_ARGUMENT, "image too large");
     if (strip_w == 0 || (uint64_t)x0 + strip_w > width)
         return set_error(MRT_ERR_INVALID_ARGUMENT, "strip exceeds the image width");
+    if ((unsigned long long)strip_w * height * (unsigned long long)spp >= (1ull << 53))
+        return set_error(MRT_ERR_INVALID_ARGUMENT, "more than 2^53 paths in one call");
     std::lock_guard<std::mutex> lock(sc->mu);
     HIP_TRY(hipSetDevice(sc->device));
+    {
+        // The accumulation adds are hardware f32 atomics, which are only defined on ordinary
+        // (coarse-grained) device memory of the scene's GPU: host, managed or another GPU's memory
+        // would silently lose samples.
+        hipPointerAttribute_t attr{};
+        const hipError_t e = hipPointerGetAttributes(&attr, accum_dev);
+        if (e != hipSuccess) (void)hipGetLastError();
+        if (e != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != sc->device)
+            return set_error(MRT_ERR_INVALID_ARGUMENT,
+                             "the accumulation buffer must be hipMalloc'ed device memory on the scene's device");
+    }
     if (stats) std::memset(stats, 0, sizeof(*stats));
     if (spp == 0) return MRT_OK;
-    int rc = ensure_pool(sc);
-    if (rc != MRT_OK) return rc;
+    Pool pools[2]{};
+    Counters* counters = nullptr;
+    unsigned long long* wave_chunks = nullptr;
+    uint32_t pool_slots = 0;
+    {
+        int rc = ensure_pool(sc);
+        if (rc != MRT_OK) return rc;
+        pools[0] = sc->pool[0], pools[1] = sc->pool[1];
+        counters = sc->counters, wave_chunks = sc->wave_chunks, pool_slots = sc->pool_slots;
+    }
+    const bool can_compact = sc->opt_compact != 0;
+    if (sc->n_events < 4 || !sc->host_counters) return set_error(MRT_ERR_DEVICE, "scene has no call resources");
+    const hipEvent_t ev_begin = sc->events[0], ev_end = sc->events[1], ek0 = sc->events[2], ek1 = sc->events[3];
+    Counters& host = *sc->host_counters;
 
     RenderParams rp{};
     rp.accum = accum_dev;
     rp.width = width, rp.height = height, rp.x0 = x0, rp.strip_w = strip_w;
     rp.npix_strip = (unsigned long long)strip_w * height;
     rp.n_work = rp.npix_strip * spp;
-    if (rp.n_work >= (1ull << 53)) return set_error(MRT_ERR_INVALID_ARGUMENT, "more than 2^53 paths in one call");
     rp.inv_npix_strip = 1.0 / (double)rp.npix_strip;
     rp.inv_strip_w = 1.0 / (double)strip_w;
     rp.seed = seed, rp.first_sample = first_sample;
     rp.steps = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(sc->opt_steps, 65536));
-    uint32_t n_slots = (uint32_t)std::min<unsigned long long>(sc->pool_slots, (rp.n_work + BLOCK - 1) / BLOCK * BLOCK);
+    uint32_t n_slots = (uint32_t)std::min<unsigned long long>(pool_slots, (rp.n_work + BLOCK - 1) / BLOCK * BLOCK);
     // Claim size. Two pulls: small claims keep the waves finishing together (only a wave's own lanes
     // start the items it holds, so with 512-item claims a small render is in effect partitioned
     // statically and waits for its slowest waves), but every claim is an atomic on ONE counter, which
@@ -2358,20 +2408,8 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     view.trace_zero_throughput = (int32_t)sc->opt_trace_zero;
     const bool wave_sync = trav != TRAV_LANE && trav != TRAV_CANDIDATES;
 
-    hipEvent_t ev_begin, ev_end, ek0, ek1;
-    HIP_TRY(hipEventCreate(&ev_begin));
-    HIP_TRY(hipEventCreate(&ev_end));
-    HIP_TRY(hipEventCreate(&ek0));
-    HIP_TRY(hipEventCreate(&ek1));
-    struct EvGuard {
-        hipEvent_t e[4];
-        ~EvGuard() {
-            for (auto x : e) (void)hipEventDestroy(x);
-        }
-    } guard{{ev_begin, ev_end, ek0, ek1}};
-
     HIP_TRY(hipEventRecord(ev_begin, stream));
-    HIP_TRY(hipMemsetAsync(sc->counters, 0, sizeof(Counters), stream));
+    HIP_TRY(hipMemsetAsync(counters, 0, sizeof(Counters), stream));
     if (sc->opt_shader != MRT_SHADER_RAYTRACING) {
         // single-bounce shaders: one thread per pixel-sample, in launches of at most 2^28 threads
         const unsigned long long per_launch = 1ull << 28;
@@ -2384,19 +2422,19 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
             dispatch_feat(sc->features, SingleBounceFeats{}, [&](auto feat) {
                 constexpr int FT = decltype(feat)::value;
                 if (wave_sync && light_map)
-                    hipLaunchKernelGGL((k_single_bounce<true, FT, MRT_SHADER_LIGHT_MAP>), grid, block, lds_bytes(true, FT, BLOCK), stream, view, rp, w0, w1, sc->counters);
+                    hipLaunchKernelGGL((k_single_bounce<true, FT, MRT_SHADER_LIGHT_MAP>), grid, block, lds_bytes(true, FT, BLOCK), stream, view, rp, w0, w1, counters);
                 else if (wave_sync)
-                    hipLaunchKernelGGL((k_single_bounce<true, FT, MRT_SHADER_DIFFUSE>), grid, block, lds_bytes(true, FT, BLOCK), stream, view, rp, w0, w1, sc->counters);
+                    hipLaunchKernelGGL((k_single_bounce<true, FT, MRT_SHADER_DIFFUSE>), grid, block, lds_bytes(true, FT, BLOCK), stream, view, rp, w0, w1, counters);
                 else if (light_map)
-                    hipLaunchKernelGGL((k_single_bounce<false, FT, MRT_SHADER_LIGHT_MAP>), grid, block, lds_bytes(false, FT, BLOCK), stream, view, rp, w0, w1, sc->counters);
+                    hipLaunchKernelGGL((k_single_bounce<false, FT, MRT_SHADER_LIGHT_MAP>), grid, block, lds_bytes(false, FT, BLOCK), stream, view, rp, w0, w1, counters);
                 else
-                    hipLaunchKernelGGL((k_single_bounce<false, FT, MRT_SHADER_DIFFUSE>), grid, block, lds_bytes(false, FT, BLOCK), stream, view, rp, w0, w1, sc->counters);
+                    hipLaunchKernelGGL((k_single_bounce<false, FT, MRT_SHADER_DIFFUSE>), grid, block, lds_bytes(false, FT, BLOCK), stream, view, rp, w0, w1, counters);
             });
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(ek1, stream));
-        Counters done{};
-        HIP_TRY(hipMemcpyAsync(&done, sc->counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+        Counters& done = host;
+        HIP_TRY(hipMemcpyAsync(&done, counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipEventRecord(ev_end, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         float ms = 0.f, total = 0.f;
@@ -2413,16 +2451,15 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
         return MRT_OK;
     }
     int cur = 0;
-    hipLaunchKernelGGL(k_init_pool, dim3(n_slots / BLOCK), dim3(BLOCK), 0, stream, sc->pool[cur], n_slots, sc->wave_chunks);
+    hipLaunchKernelGGL(k_init_pool, dim3(n_slots / BLOCK), dim3(BLOCK), 0, stream, pools[cur], n_slots, wave_chunks);
     HIP_TRY(hipGetLastError());
 
-    Counters host{};
     double kernel_ms = 0.0;
     uint64_t launches = 0;
     uint32_t active = n_slots;
     unsigned long long handed_before = 0;
     for (;;) {
-        HIP_TRY(hipMemsetAsync(&sc->counters->live, 0, sizeof(unsigned int) * 2 + sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(&counters->live, 0, sizeof(unsigned int) * 2 + sizeof(unsigned long long), stream));
         rp.n_slots = active;
         HIP_TRY(hipEventRecord(ek0, stream));
         {
@@ -2431,15 +2468,15 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
                 constexpr int FT = decltype(feat)::value;
                 if (wave_sync)
                     hipLaunchKernelGGL((k_segments<true, FT>), dim3(active / seg_block(true)), dim3(seg_block(true)),
-                                       lds_bytes(true, FT, seg_block(true)), stream, view, sc->pool[cur], rp, sc->counters, sc->wave_chunks);
+                                       lds_bytes(true, FT, seg_block(true)), stream, view, pools[cur], rp, counters, wave_chunks);
                 else
                     hipLaunchKernelGGL((k_segments<false, FT>), dim3(active / seg_block(false)), dim3(seg_block(false)),
-                                       lds_bytes(false, FT, seg_block(false)), stream, view, sc->pool[cur], rp, sc->counters, sc->wave_chunks);
+                                       lds_bytes(false, FT, seg_block(false)), stream, view, pools[cur], rp, counters, wave_chunks);
             });
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ek1, stream));
-        HIP_TRY(hipMemcpyAsync(&host, sc->counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(&host, counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ek0, ek1));
@@ -2460,17 +2497,18 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
             handed_before = handed;
         }
         bool work_left = host.work_next < rp.n_work || host.held > 0;
+        rp.all_claimed = host.work_next >= rp.n_work ? 1u : 0u;  // later launches need not ask the counter again
         if (!work_left && host.live == 0) break;
-        if (!work_left && sc->opt_compact && host.live * 4ull < (unsigned long long)active * 3ull && active > BLOCK) {
+        if (!work_left && can_compact && host.live * 4ull < (unsigned long long)active * 3ull && active > BLOCK) {
             // drain phase: pack the survivors so that later launches cover only live paths
-            hipLaunchKernelGGL(k_compact, dim3((active + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, sc->pool[cur],
-                               sc->pool[cur ^ 1], active, sc->counters);
+            hipLaunchKernelGGL(k_compact, dim3((active + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, stream, pools[cur],
+                               pools[cur ^ 1], active, counters);
             HIP_TRY(hipGetLastError());
             cur ^= 1;
             active = (host.live + BLOCK - 1) / BLOCK * BLOCK;
             if (active > host.live) {
                 // slots between live and the block boundary must read as free
-                HIP_TRY(hipMemsetAsync(sc->pool[cur].seg + host.live, 0xFF, sizeof(int32_t) * (active - host.live), stream));
+                HIP_TRY(hipMemsetAsync(pools[cur].seg + host.live, 0xFF, sizeof(int32_t) * (active - host.live), stream));
             }
         }
         if (launches > 100000000ull) return set_error(MRT_ERR_DEVICE, "render loop did not terminate");
@@ -2503,6 +2541,185 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
         stats->total_ms = total_ms;
         stats->segment_kernel_avg_ms = launches ? kernel_ms / (double)launches : 0.0;
     }
+    return MRT_OK;
+}
+
+// ---- RCCL, bound at first use (no link-time dependency: single-GPU hosts never load it)
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclCommInitAll) comm_init_all = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    bool ok = false;
+    // one communicator set per device list, kept for the life of the process
+    std::map<std::vector<int>, std::vector<ncclComm_t>> comms;
+};
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) return;
+        r.comm_init_all = reinterpret_cast<decltype(r.comm_init_all)>(dlsym(r.lib, "ncclCommInitAll"));
+        r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(r.lib, "ncclCommDestroy"));
+        r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(dlsym(r.lib, "ncclAllReduce"));
+        r.group_start = reinterpret_cast<decltype(r.group_start)>(dlsym(r.lib, "ncclGroupStart"));
+        r.group_end = reinterpret_cast<decltype(r.group_end)>(dlsym(r.lib, "ncclGroupEnd"));
+        r.error_string = reinterpret_cast<decltype(r.error_string)>(dlsym(r.lib, "ncclGetErrorString"));
+        r.ok = r.comm_init_all && r.comm_destroy && r.all_reduce && r.group_start && r.group_end && r.error_string;
+    });
+    return r;
+}
+std::mutex g_multi_mu;  // mrt_render_accumulate_multi calls take turns (resident images, communicators)
+
+// In-place sum of one f32 image per device over all devices: one ncclAllReduce per device inside one
+// group call (RCCL over xGMI between GPUs; a copy when there is one device). Returns false with
+// `why` set when RCCL is unavailable or fails; the caller then sums on the host.
+bool all_reduce_images(const std::vector<int>& devices, const std::vector<float*>& images, size_t n_float, std::string& why) {
+    Rccl& r = rccl();
+    if (!r.ok) {
+        why = "librccl could not be loaded";
+        return false;
+    }
+    auto it = r.comms.find(devices);
+    if (it == r.comms.end()) {
+        std::vector<ncclComm_t> c(devices.size());
+        const ncclResult_t rc = r.comm_init_all(c.data(), (int)devices.size(), devices.data());
+        if (rc != ncclSuccess) {
+            why = std::string("ncclCommInitAll: ") + r.error_string(rc);
+            return false;
+        }
+        it = r.comms.emplace(devices, std::move(c)).first;
+    }
+    ncclResult_t rc = r.group_start();
+    for (size_t g = 0; g < devices.size() && rc == ncclSuccess; ++g) {
+        if (hipSetDevice(devices[g]) != hipSuccess) rc = ncclUnhandledCudaError;
+        else rc = r.all_reduce(images[g], images[g], n_float, ncclFloat, ncclSum, it->second[g], nullptr);
+    }
+    const ncclResult_t rc_end = r.group_end();
+    if (rc == ncclSuccess) rc = rc_end;
+    bool synced = true;
+    for (size_t g = 0; g < devices.size(); ++g)
+        synced = hipSetDevice(devices[g]) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess && synced;
+    if (rc != ncclSuccess || !synced) {
+        why = rc != ncclSuccess ? std::string("ncclAllReduce: ") + r.error_string(rc) : "synchronisation after the all-reduce failed";
+        return false;
+    }
+    return true;
+}
+
+// Body of mrt_render_accumulate_multi (arguments checked by the caller). Each GPU holds ONE resident
+// accumulation image (owned by the first handle on it; several handles on a GPU add into it together,
+// the adds are atomic). The strip of the host image is uploaded once, to the first GPU; the per-GPU
+// images are summed on the devices; the strip is downloaded once.
+int render_multi(mrt_scene* const* scenes, uint32_t n_scenes, float* accum_rgb, uint32_t width, uint32_t height,
+                 uint32_t x0, uint32_t strip_w, uint32_t spp, uint64_t seed, uint64_t first_sample_index, mrt_stats* stats) {
+    std::lock_guard<std::mutex> turn(g_multi_mu);
+    const auto t_begin = std::chrono::steady_clock::now();
+    const size_t n_float = 3 * (size_t)width * height;
+    struct Share {
+        mrt_stats stats{};
+        int rc = MRT_OK;
+        std::string message;
+        uint32_t spp = 0;
+        uint64_t first = 0;
+        size_t group = 0;
+    };
+    std::vector<Share> shares(n_scenes);
+    std::vector<int> devices;       // distinct devices, in order of first use
+    std::vector<mrt_scene*> owners; // first handle on each device: holds the device's image
+    uint64_t next = first_sample_index;
+    for (uint32_t i = 0; i < n_scenes; ++i) {
+        shares[i].spp = spp / n_scenes + (i < spp % n_scenes ? 1u : 0u);
+        shares[i].first = next;
+        next += shares[i].spp;
+        size_t g = std::find(devices.begin(), devices.end(), scenes[i]->device) - devices.begin();
+        if (g == devices.size()) devices.push_back(scenes[i]->device), owners.push_back(scenes[i]);
+        shares[i].group = g;
+    }
+    std::vector<float*> images(devices.size(), nullptr);
+    const size_t host_pitch = sizeof(float) * 3 * (size_t)width, strip_bytes = sizeof(float) * 3 * (size_t)strip_w;
+    for (size_t g = 0; g < devices.size(); ++g) {
+        mrt_scene* o = owners[g];
+        HIP_TRY(hipSetDevice(devices[g]));
+        if (o->multi_accum_floats != n_float) {
+            if (o->multi_accum) (void)hipFree(o->multi_accum);
+            o->multi_accum = nullptr, o->multi_accum_floats = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&o->multi_accum), sizeof(float) * n_float));
+            o->multi_accum_floats = n_float;
+        }
+        images[g] = o->multi_accum;
+        HIP_TRY(hipMemset(images[g], 0, sizeof(float) * n_float));
+        if (g == 0)  // the host image's strip joins the sum through the first device
+            HIP_TRY(hipMemcpy2D(images[0] + 3 * (size_t)x0, host_pitch, accum_rgb + 3 * (size_t)x0, host_pitch, strip_bytes, height,
+                                hipMemcpyHostToDevice));
+    }
+    {
+        std::vector<std::thread> workers;
+        struct Joiner {
+            std::vector<std::thread>& w;
+            ~Joiner() {
+                for (std::thread& t : w)
+                    if (t.joinable()) t.join();
+            }
+        } joiner{workers};
+        workers.reserve(n_scenes);
+        for (uint32_t i = 0; i < n_scenes; ++i) {
+            if (shares[i].spp == 0) continue;
+            workers.emplace_back([&, i] {
+                Share& s = shares[i];
+                try {
+                    s.rc = render_device(scenes[i], images[s.group], width, height, x0, strip_w, s.spp, seed, s.first, nullptr, &s.stats);
+                    if (s.rc != MRT_OK) s.message = g_last_error;  // the worker thread's message
+                } catch (const std::exception& e) {
+                    s.rc = MRT_ERR_OUT_OF_MEMORY, s.message = e.what();
+                }
+            });
+        }
+    }
+    for (const Share& s : shares)
+        if (s.rc != MRT_OK) return set_error(s.rc, s.message);
+    // join the per-device images: on the devices when RCCL is there (always for several devices; for one
+    // device only when MRT_MULTI_FORCE_RCCL is set, which lets a one-GPU host exercise the collective)
+    const bool want_collective = devices.size() > 1 || std::getenv("MRT_MULTI_FORCE_RCCL") != nullptr;
+    bool reduced = devices.size() == 1;
+    std::string why;
+    if (want_collective) {
+        reduced = all_reduce_images(devices, images, n_float, why) || devices.size() == 1;
+        if (std::getenv("MRT_MULTI_FORCE_RCCL") != nullptr && !why.empty()) return set_error(MRT_ERR_DEVICE, why);
+    }
+    HIP_TRY(hipSetDevice(devices[0]));
+    HIP_TRY(hipMemcpy2D(accum_rgb + 3 * (size_t)x0, host_pitch, images[0] + 3 * (size_t)x0, host_pitch, strip_bytes, height,
+                        hipMemcpyDeviceToHost));
+    if (!reduced) {
+        // no collective: the other devices' strips are added on the host, in device order
+        std::vector<float> tmp((size_t)strip_w * 3 * height);
+        for (size_t g = 1; g < devices.size(); ++g) {
+            HIP_TRY(hipSetDevice(devices[g]));
+            HIP_TRY(hipMemcpy2D(tmp.data(), strip_bytes, images[g] + 3 * (size_t)x0, host_pitch, strip_bytes, height, hipMemcpyDeviceToHost));
+            for (uint32_t y = 0; y < height; ++y) {
+                float* dst = accum_rgb + ((size_t)y * width + x0) * 3;
+                const float* src = tmp.data() + (size_t)y * strip_w * 3;
+                for (size_t k = 0; k < (size_t)strip_w * 3; ++k) dst[k] += src[k];
+            }
+        }
+    }
+    mrt_stats total{};
+    for (const Share& s : shares) {
+        if (s.spp == 0) continue;
+        total.paths += s.stats.paths, total.rays += s.stats.rays, total.light_queries += s.stats.light_queries;
+        total.launches += s.stats.launches;
+        total.kernel_ms = std::max(total.kernel_ms, s.stats.kernel_ms);
+        total.segment_kernel_avg_ms = std::max(total.segment_kernel_avg_ms, s.stats.segment_kernel_avg_ms);
+    }
+    total.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    if (stats) *stats = total;
     return MRT_OK;
 }
 
@@ -2558,7 +2775,7 @@ mrt_scene* mrt_scene_create(const mrt_scene_desc* desc, int device, char* err, s
             report("hipSetDevice failed");
             return nullptr;
         }
-        if (upload_scene(sc.get()) != MRT_OK) {
+        if (upload_scene(sc.get()) != MRT_OK || create_call_resources(sc.get()) != MRT_OK) {
             report(g_last_error);
             return nullptr;
         }
@@ -2715,51 +2932,13 @@ int mrt_render_accumulate_multi(mrt_scene* const* scenes, uint32_t n_scenes, flo
     if (width < 2 || height < 2 || (uint64_t)width * height > 0xFFFFFFFFull / 3)
         return set_error(MRT_ERR_INVALID_ARGUMENT, "bad image size");
     if (x0 >= width || strip_w == 0 || strip_w > width - x0) return set_error(MRT_ERR_INVALID_ARGUMENT, "strip outside the image");
-    const auto t_begin = std::chrono::steady_clock::now();
-    const size_t n_float = 3 * (size_t)width * height;
-    struct Share {
-        std::vector<float> image;
-        mrt_stats stats{};
-        int rc = MRT_OK;
-        std::string message;
-        uint32_t spp = 0;
-        uint64_t first = 0;
-    };
-    std::vector<Share> shares(n_scenes);
-    uint64_t next = first_sample_index;
-    for (uint32_t i = 0; i < n_scenes; ++i) {
-        shares[i].spp = spp / n_scenes + (i < spp % n_scenes ? 1u : 0u);
-        shares[i].first = next;
-        next += shares[i].spp;
+    try {
+        return render_multi(scenes, n_scenes, accum_rgb, width, height, x0, strip_w, spp, seed, first_sample_index, stats);
+    } catch (const std::bad_alloc&) {
+        return set_error(MRT_ERR_OUT_OF_MEMORY, "out of host memory");
+    } catch (const std::exception& e) {
+        return set_error(MRT_ERR_DEVICE, e.what());
     }
-    std::vector<std::thread> workers;
-    for (uint32_t i = 0; i < n_scenes; ++i) {
-        if (shares[i].spp == 0) continue;
-        workers.emplace_back([&, i] {
-            Share& s = shares[i];
-            s.image.assign(n_float, 0.0f);
-            s.rc = mrt_render_accumulate(scenes[i], s.image.data(), width, height, x0, strip_w, s.spp, seed, s.first, &s.stats);
-            if (s.rc != MRT_OK) s.message = g_last_error;  // the worker thread's message
-        });
-    }
-    for (std::thread& w : workers) w.join();
-    for (const Share& s : shares)
-        if (s.rc != MRT_OK) return set_error(s.rc, s.message);
-    mrt_stats total{};
-    for (const Share& s : shares) {
-        if (s.spp == 0) continue;
-        for (uint32_t y = 0; y < height; ++y) {
-            const size_t row = ((size_t)y * width + x0) * 3;
-            for (size_t k = row; k < row + (size_t)strip_w * 3; ++k) accum_rgb[k] += s.image[k];
-        }
-        total.paths += s.stats.paths, total.rays += s.stats.rays, total.light_queries += s.stats.light_queries;
-        total.launches += s.stats.launches;
-        total.kernel_ms = std::max(total.kernel_ms, s.stats.kernel_ms);
-        total.segment_kernel_avg_ms = std::max(total.segment_kernel_avg_ms, s.stats.segment_kernel_avg_ms);
-    }
-    total.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    if (stats) *stats = total;
-    return MRT_OK;
 }
 
 int mrt_to_image(const float* accum_rgb, uint32_t width, uint32_t height, uint32_t num_samples, uint8_t* rgb8_out) {

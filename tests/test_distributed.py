@@ -65,3 +65,42 @@ def test_two_rank_spp_split_equals_single_render(tmp_path):
     single, _ = OracleWorld(scenarios.cornell_smoke()).render(20, 20, total_spp, seed=4, threads=2)
     # same pixel-samples, different f32 summation order
     np.testing.assert_allclose(sharded, single, rtol=1e-5, atol=1e-6)
+
+
+def _run_bench(*flags):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *flags], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks_weak_and_strong():
+    """`bench.py --gpus 2` without a launcher forks two fresh ranks, joins them over the process group and prints
+    ONE line with n_gpus 2 (rehearsed on CPUs: gloo, no rendering). Every rank adds 1 per sample it owns, so the
+    all-reduced image divided by the total sample count is exactly 1 when the shares cover the range once."""
+    weak = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", "--steps", "2", "--warmup", "1", "--width", "32",
+                      "--height", "16", "--spp", "4")
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["dry"] is True
+    assert weak["mean_radiance"] == 1.0
+    assert weak["value"] > 0 and abs(weak["value"] * weak["ms_per_step"] * 1e3 - 32 * 16 * 4 * 2) < 1e-3 * 32 * 16 * 8
+    strong = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", "--strong", "--steps", "1", "--warmup", "0",
+                        "--width", "32", "--height", "16", "--spp", "5")
+    assert strong["n_gpus"] == 2 and strong["scaling"] == "strong" and strong["mean_radiance"] == 1.0
+    assert abs(strong["value"] * strong["ms_per_step"] * 1e3 - 32 * 16 * 5) < 1e-3 * 32 * 16 * 5
+
+
+def test_bench_refuses_a_launcher_with_another_world_size():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry", "--backend", "gloo"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)

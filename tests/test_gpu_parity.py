@@ -325,3 +325,83 @@ def test_samples_split_over_scene_handles_in_one_process():
     from ray_tracing_amd import _ffi as F
     lib = F.load()
     assert lib.mrt_render_accumulate_multi(None, 0, img2.buffer.ctypes.data, W, H, 0, W, 1, 0, 0, None) == F.MRT_ERR_INVALID_ARGUMENT
+
+
+def test_multi_handle_sum_through_rccl_world_of_one(monkeypatch):
+    """The device-side join of mrt_render_accumulate_multi: with MRT_MULTI_FORCE_RCCL the per-device images go
+    through ncclAllReduce even on one GPU (a communicator of one rank), and a failure of the collective is an
+    error instead of a fall-back to the host sum."""
+    monkeypatch.setenv("MRT_MULTI_FORCE_RCCL", "1")
+    info = scenarios.cornell_smoke()
+    rts = [RayTracer(info, device=0, seed=8) for _ in range(2)]
+    W, H, spp = 64, 40, 5
+    img = ParallelImage(np.full((H, W, 3), 0.25, dtype=np.float32))
+    st = rts[0].trace_part_multi(rts[1:], img.split(1)[0], spp, first_sample=2)
+    assert st.paths == W * H * spp
+    monkeypatch.delenv("MRT_MULTI_FORCE_RCCL")
+    ref, _ = gpu_render(rts[0], W, H, spp, first=2)
+    np.testing.assert_allclose(img.buffer, ref + np.float32(0.25), rtol=1e-5, atol=1e-6)
+    # twice in a row with another image size: the resident per-device image is re-made
+    img2 = ParallelImage.new_black(50, 30)
+    rts[0].trace_part_multi(rts[1:], img2.split(1)[0], 3, first_sample=0)
+    ref2, _ = gpu_render(rts[0], 50, 30, 3, first=0)
+    np.testing.assert_allclose(img2.buffer, ref2, rtol=1e-5, atol=1e-6)
+
+
+def test_render_sharded_over_nccl_world_of_one(worlds):
+    """The multi-process leg of the benchmark on the one GPU that is here: a process group over the "nccl" backend
+    (RCCL) with one rank, this rank's share rendered into a device tensor, one all-reduce of that tensor."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from ray_tracing_amd.distributed import render_sharded
+    info, rt, ow = worlds("Cornell Smoke", seed=3)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    W, H, spp = 96, 54, 6
+    accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        def render(first, count):
+            rt.render_device(accum.data_ptr(), W, H, count, first_sample=first,
+                             stream=torch.cuda.current_stream().cuda_stream)
+
+        reduced = []
+
+        def all_reduce():
+            dist.all_reduce(accum)
+            reduced.append(True)
+
+        first, count = render_sharded(render, all_reduce, spp, 0, 1, first_sample=4)
+        assert (first, count) == (4, spp) and not reduced      # one rank: nothing to join
+        dist.all_reduce(accum)                                  # the collective itself, on the device buffer
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    ref, _ = gpu_render(rt, W, H, spp, first=4)
+    np.testing.assert_allclose(accum.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_full_size_properties_cornell_4k(worlds):
+    """One GPU's share of the eight-GPU configuration (Cornell smoke 3840x2160, samples split by index)."""
+    from ray_tracing_amd.distributed import sample_range
+    info, rt, ow = worlds("Cornell Smoke", seed=3)
+    W, H = 3840, 2160
+    a, sa = gpu_render(rt, W, H, 2, first=0)
+    # two ranks' shares of a 2-sample render, accumulated into one buffer, are the one-call render
+    b = np.zeros((H, W, 3), dtype=np.float32)
+    for r in range(2):
+        first, count = sample_range(2, r, 2)
+        gpu_render(rt, W, H, count, first=first, accum=b)
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+    assert sa.paths == W * H * 2 and sa.paths <= sa.rays <= 50 * sa.paths
+    assert np.isfinite(a).all() and a.min() >= 0.0 and a.max() <= 7.0 * 2 * 1.0001
+    ref, _ = ow.render(240, 135, 32, seed=77, threads=16)
+    np.testing.assert_allclose(a.mean(axis=(0, 1), dtype=np.float64) / 2, ref.mean(axis=(0, 1), dtype=np.float64) / 32,
+                               rtol=0.03)
+    assert a[800:1400, 10:120].max() == 0.0 and a[1000:1120, 1860:1980].max() == 0.0   # green wall / back wall black
