@@ -360,6 +360,28 @@ int mrt_render_accumulate_device(mrt_scene* scene, float* accum_rgb_device, uint
                                  uint64_t seed, uint64_t first_sample_index, void* stream,
                                  mrt_stats* stats);
 
+/* mrt_render_accumulate_device for callers that cannot allocate (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc). It has no counterpart in the reference.
+ * Same arguments, same samples and the same image (up to the order of the f32 additions), but the
+ * call allocates nothing on the device or the host: the path pool, the counters and the per-wave
+ * work ranges live in a device array that is part of the library's code object
+ * (MRT_NOALLOC_SCRATCH_BYTES bytes on every GPU the library runs on, held until the process
+ * ends), and the events and the pinned counter copy were created with the scene.
+ * Limits: the pool is MRT_NOALLOC_POOL_SLOTS path slots whatever "pool_slots" says, and the drain
+ * phase does not pack the pool ("compaction" is ignored); neither grows with the image, so the
+ * sizes that are rejected (MRT_ERR_INVALID_ARGUMENT) are those of every render entry point:
+ * width * height > (2^32 - 1) / 3 pixels, strip_w * height * spp >= 2^53 paths, a strip outside
+ * the image. Every call on a GPU uses that GPU's one array, which keeps the previous call's
+ * contents (each call resets what it reads): calls on one GPU, from any thread and for any scene,
+ * take turns on a per-GPU lock inside the library; a second PROCESS's calls are not ordered
+ * against it but have their own copy of the array. */
+#define MRT_NOALLOC_POOL_SLOTS 196608u
+#define MRT_NOALLOC_SCRATCH_BYTES 16564736u
+int mrt_render_accumulate_device_noalloc(mrt_scene* scene, float* accum_rgb_device, uint32_t width,
+                                         uint32_t height, uint32_t x0, uint32_t strip_w, uint32_t spp,
+                                         uint64_t seed, uint64_t first_sample_index, void* stream,
+                                         mrt_stats* stats);
+
 /* `ParallelImage / num_samples` (parallel_image.rs:268-278) followed by
  * `to_image`'s colour mapping (parallel_image.rs:35-65, rgb_color.rs:75-80):
  * rgb8_out[(x + (height-1-y)*width)*3 + c] = round(clamp(sqrt(accum/spp))*255).

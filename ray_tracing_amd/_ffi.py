@@ -122,7 +122,7 @@ class Stats(C.Structure):
 EXPORTS = [
     "mrt_abi_version", "mrt_device_count", "mrt_last_error", "mrt_scene_create", "mrt_scene_destroy",
     "mrt_scene_bvh", "mrt_camera_rays", "mrt_trace_rays", "mrt_render_accumulate",
-    "mrt_render_accumulate_device", "mrt_render_accumulate_multi", "mrt_to_image", "mrt_scene_set_option",
+    "mrt_render_accumulate_device", "mrt_render_accumulate_device_noalloc", "mrt_render_accumulate_multi", "mrt_to_image", "mrt_scene_set_option",
     "mrt_bloom_device", "mrt_bloom", "mrt_to_image_device",
     "mrt_voxels_create", "mrt_voxels_destroy", "mrt_voxels_set", "mrt_voxels_combine", "mrt_voxels_load_vox",
     "mrt_voxels_count", "mrt_voxels_linearise",
@@ -164,6 +164,8 @@ def load() -> C.CDLL:
     lib.mrt_render_accumulate.argtypes = [vp, vp, u32, u32, u32, u32, u32, u64, u64, C.POINTER(Stats)]
     lib.mrt_render_accumulate_device.restype = C.c_int
     lib.mrt_render_accumulate_device.argtypes = [vp, vp, u32, u32, u32, u32, u32, u64, u64, vp, C.POINTER(Stats)]
+    lib.mrt_render_accumulate_device_noalloc.restype = C.c_int
+    lib.mrt_render_accumulate_device_noalloc.argtypes = [vp, vp, u32, u32, u32, u32, u32, u64, u64, vp, C.POINTER(Stats)]
     lib.mrt_render_accumulate_multi.restype = C.c_int
     lib.mrt_render_accumulate_multi.argtypes = [vp, u32, vp, u32, u32, u32, u32, u32, u64, u64, C.POINTER(Stats)]
     lib.mrt_to_image.restype = C.c_int

@@ -2124,6 +2124,35 @@ __global__ void __launch_bounds__(BLOCK) k_trace_rays(SceneView sv, const double
 // ====================================================================== host side
 using namespace mrt;
 
+// ---- device memory of mrt_render_accumulate_device_noalloc, the render entry point that allocates
+// nothing: one path pool of NOALLOC_SLOTS slots (3072 waves = three waves per SIMD of a 256-CU GPU,
+// i.e. one generation of resident waves), the counters and the per-wave work ranges, in a
+// file-scope device array that every GPU the library runs on holds until the process ends.
+// In host code the array's name is only a handle for hipGetSymbolAddress; the address the kernels
+// get is the per-device pointer resolved by resolve_scratch().
+constexpr uint32_t NOALLOC_SLOTS = 3072u * 64u;
+constexpr size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
+struct ScratchLayout {
+    size_t f64[7], f32[3], pixel, key, seg, counters, wave_chunks, total;
+};
+constexpr ScratchLayout scratch_layout() {
+    ScratchLayout l{};
+    size_t off = 0;
+    for (int i = 0; i < 7; ++i) l.f64[i] = off, off += align256(sizeof(double) * NOALLOC_SLOTS);
+    for (int i = 0; i < 3; ++i) l.f32[i] = off, off += align256(sizeof(float) * NOALLOC_SLOTS);
+    l.pixel = off, off += align256(sizeof(uint32_t) * NOALLOC_SLOTS);
+    l.key = off, off += align256(sizeof(uint64_t) * NOALLOC_SLOTS);
+    l.seg = off, off += align256(sizeof(int32_t) * NOALLOC_SLOTS);
+    l.counters = off, off += align256(sizeof(Counters));
+    l.wave_chunks = off, off += align256(sizeof(unsigned long long) * 2 * (NOALLOC_SLOTS / 64));
+    l.total = off;
+    return l;
+}
+constexpr ScratchLayout SCRATCH = scratch_layout();
+static_assert(NOALLOC_SLOTS == MRT_NOALLOC_POOL_SLOTS && SCRATCH.total == MRT_NOALLOC_SCRATCH_BYTES,
+              "include/mrt.h states the pool slots and the bytes of the scratch array");
+static __device__ __align__(256) unsigned char scratch[SCRATCH.total];
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -2327,6 +2356,32 @@ int ensure_pool(mrt_scene* sc) {
     return MRT_OK;
 }
 
+// Per-device address of `scratch` (each GPU holds its own copy of the array at its own address),
+// resolved once per device with that device current, and a lock per device: every call on a GPU
+// shares that GPU's array, so calls of the no-allocation entry point on one GPU take turns.
+constexpr int MAX_DEVICES = 64;
+struct ScratchDevice {
+    unsigned char* ptr = nullptr;
+    hipError_t status = hipSuccess;
+    bool resolved = false;
+    std::mutex in_use;
+};
+ScratchDevice g_scratch_dev[MAX_DEVICES];
+std::mutex g_scratch_mu;
+// Requires `device` to be the current device.
+hipError_t resolve_scratch(int device) {
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    ScratchDevice& d = g_scratch_dev[device];
+    if (!d.resolved) {
+        void* p = nullptr;
+        d.status = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        d.ptr = d.status == hipSuccess ? static_cast<unsigned char*>(p) : nullptr;
+        d.resolved = true;
+    }
+    return d.status;
+}
+
 // Events and the pinned counter copy of a scene (created once, with the scene's device current).
 int create_call_resources(mrt_scene* sc) {
     for (; sc->n_events < 4; ++sc->n_events) HIP_TRY(hipEventCreate(&sc->events[sc->n_events]));
@@ -2334,9 +2389,12 @@ int create_call_resources(mrt_scene* sc) {
     return MRT_OK;
 }
 
-// Render loop on `stream`; accum is device memory.
+// Render loop on `stream`; accum is device memory. With `scratch_ptr` (this device's address of
+// `scratch`) the pool, the counters and the work ranges are carved from it and nothing is allocated;
+// otherwise they are the scene's own (allocated on its first render).
 int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t height, uint32_t x0, uint32_t strip_w,
-                  uint32_t spp, uint64_t seed, uint64_t first_sample, hipStream_t stream, mrt_stats* stats) {
+                  uint32_t spp, uint64_t seed, uint64_t first_sample, hipStream_t stream, mrt_stats* stats,
+                  unsigned char* scratch_ptr = nullptr) {
     if (!sc || sc->device < 0) return set_error(MRT_ERR_INVALID_ARGUMENT, "scene has no device image");
     if (!accum_dev) return set_error(MRT_ERR_INVALID_ARGUMENT, "accumulation buffer is NULL");
     if (width < 2 || height < 2) return set_error(MRT_ERR_INVALID_ARGUMENT, "image must be at least 2x2");
@@ -2364,13 +2422,25 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     Counters* counters = nullptr;
     unsigned long long* wave_chunks = nullptr;
     uint32_t pool_slots = 0;
-    {
+    if (scratch_ptr) {
+        Pool& p = pools[0];
+        double** d7[7] = {&p.ox, &p.oy, &p.oz, &p.dx, &p.dy, &p.dz, &p.tm};
+        for (int i = 0; i < 7; ++i) *d7[i] = reinterpret_cast<double*>(scratch_ptr + SCRATCH.f64[i]);
+        float** f3[3] = {&p.tr, &p.tg, &p.tb};
+        for (int i = 0; i < 3; ++i) *f3[i] = reinterpret_cast<float*>(scratch_ptr + SCRATCH.f32[i]);
+        p.pixel = reinterpret_cast<uint32_t*>(scratch_ptr + SCRATCH.pixel);
+        p.key = reinterpret_cast<uint64_t*>(scratch_ptr + SCRATCH.key);
+        p.seg = reinterpret_cast<int32_t*>(scratch_ptr + SCRATCH.seg);
+        counters = reinterpret_cast<Counters*>(scratch_ptr + SCRATCH.counters);
+        wave_chunks = reinterpret_cast<unsigned long long*>(scratch_ptr + SCRATCH.wave_chunks);
+        pool_slots = NOALLOC_SLOTS;
+    } else {
         int rc = ensure_pool(sc);
         if (rc != MRT_OK) return rc;
         pools[0] = sc->pool[0], pools[1] = sc->pool[1];
         counters = sc->counters, wave_chunks = sc->wave_chunks, pool_slots = sc->pool_slots;
     }
-    const bool can_compact = sc->opt_compact != 0;
+    const bool can_compact = !scratch_ptr && sc->opt_compact;  // the scratch holds one pool: no ping-pong partner
     if (sc->n_events < 4 || !sc->host_counters) return set_error(MRT_ERR_DEVICE, "scene has no call resources");
     const hipEvent_t ev_begin = sc->events[0], ev_end = sc->events[1], ek0 = sc->events[2], ek1 = sc->events[3];
     Counters& host = *sc->host_counters;
@@ -2779,6 +2849,9 @@ mrt_scene* mrt_scene_create(const mrt_scene_desc* desc, int device, char* err, s
             report(g_last_error);
             return nullptr;
         }
+        // set-up step of the no-allocation entry point: this device's address of its scratch array
+        // (a failure is reported by that entry point, not here)
+        (void)resolve_scratch(device);
     }
     return sc.release();
 }
@@ -2900,6 +2973,21 @@ int mrt_render_accumulate_device(mrt_scene* scene, float* accum_rgb_device, uint
                                  uint64_t first_sample_index, void* stream, mrt_stats* stats) {
     return render_device(scene, accum_rgb_device, width, height, x0, strip_w, spp, seed, first_sample_index,
                          static_cast<hipStream_t>(stream), stats);
+}
+
+int mrt_render_accumulate_device_noalloc(mrt_scene* scene, float* accum_rgb_device, uint32_t width, uint32_t height,
+                                         uint32_t x0, uint32_t strip_w, uint32_t spp, uint64_t seed,
+                                         uint64_t first_sample_index, void* stream, mrt_stats* stats) {
+    if (!scene || scene->device < 0) return set_error(MRT_ERR_INVALID_ARGUMENT, "scene has no device image");
+    if (scene->device >= MAX_DEVICES) return set_error(MRT_ERR_UNSUPPORTED, "device ordinal beyond the scratch table");
+    HIP_TRY(hipSetDevice(scene->device));
+    const hipError_t e = resolve_scratch(scene->device);  // resolved when the scene was created
+    if (e != hipSuccess)
+        return set_error(MRT_ERR_DEVICE, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+    ScratchDevice& dev = g_scratch_dev[scene->device];
+    std::lock_guard<std::mutex> turn(dev.in_use);  // one call at a time per GPU: they share its array
+    return render_device(scene, accum_rgb_device, width, height, x0, strip_w, spp, seed, first_sample_index,
+                         static_cast<hipStream_t>(stream), stats, dev.ptr);
 }
 
 int mrt_render_accumulate(mrt_scene* scene, float* accum_rgb, uint32_t width, uint32_t height, uint32_t x0,
