@@ -158,8 +158,15 @@ def easy_scene(earthmap: np.ndarray, perlin_seed: int = 0) -> WorldInfo:
                      CameraInfo(1.0, 20.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
 
 
+def load_earthmap_fixture(path: str) -> np.ndarray:
+    """The decoded assets/earthmap.jpg (tests/golden/earthmap_rgb8.npz, made by tests/golden/make_earthmap.py)
+    as the reference stores it: float32 (H, W, 3), texel = u8 / 255, row 0 = top row (texture.rs:196-215)."""
+    rgb8 = np.load(path)["rgb8"]
+    return rgb8.astype(np.float32) / np.float32(255.0)
+
+
 def synthetic_earthmap(width: int = 256, height: int = 128) -> np.ndarray:
-    """A deterministic stand-in for assets/earthmap.jpg with u8/255 texel values."""
+    """A deterministic image with u8/255 texel values, for generated test scenes (not the reference's asset)."""
     y, x = np.mgrid[0:height, 0:width]
     r = ((x * 7 + y * 3) % 256).astype(np.float32) / np.float32(255.0)
     g = ((x * 2 + y * 11) % 256).astype(np.float32) / np.float32(255.0)
@@ -428,8 +435,10 @@ SCENARIOS: Dict[str, Callable[[], WorldInfo]] = {
 
 
 def build(name: str, earthmap: Optional[np.ndarray] = None) -> WorldInfo:
-    if name == "Light Demonstration":
-        return light_demo(earthmap if earthmap is not None else synthetic_earthmap())
-    if name == "Easy Scene":
-        return easy_scene(earthmap if earthmap is not None else synthetic_earthmap())
+    """Scenario by its display name. The two scenarios with an image texture need the decoded
+    assets/earthmap.jpg (`load_earthmap_fixture`)."""
+    if name in ("Light Demonstration", "Easy Scene"):
+        if earthmap is None:
+            raise ValueError(f"{name!r} needs the decoded earthmap image (scenarios.load_earthmap_fixture)")
+        return light_demo(earthmap) if name == "Light Demonstration" else easy_scene(earthmap)
     return SCENARIOS[name]()

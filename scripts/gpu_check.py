@@ -2,12 +2,13 @@
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+from tests.helpers import scene_by_name
 from ray_tracing_amd import scenarios, RayTracer, ParallelImage, World
 from tests.oracle_ffi import OracleWorld
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "Cornell Smoke"
-    info = scenarios.build(name)
+    info = scene_by_name(name)
     ow = OracleWorld(info)
     rt = RayTracer(info, device=0, seed=7)
     gw = rt.world

@@ -3,13 +3,14 @@ import sys, os, time, itertools
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
+from tests.helpers import scene_by_name
 from ray_tracing_amd import scenarios, RayTracer
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "Cornell Smoke"
     spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     W, H = 1920, 1080
-    info = scenarios.build(name)
+    info = scene_by_name(name)
     rt = RayTracer(info, device=0, seed=0)
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     configs = [dict(segments_per_launch=s, pool_slots=p) for s in (2, 4, 8, 16) for p in (1 << 21, 1 << 22, 1 << 23)]

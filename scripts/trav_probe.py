@@ -1,8 +1,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+from tests.helpers import scene_by_name
 from ray_tracing_amd import scenarios, RayTracer
-info = scenarios.build(sys.argv[1] if len(sys.argv) > 1 else "Cornell Smoke")
+info = scene_by_name(sys.argv[1] if len(sys.argv) > 1 else "Cornell Smoke")
 rt = RayTracer(info, device=0, seed=3)
 W, H = 1920, 1080
 ys, xs = np.mgrid[0:H, 0:W]

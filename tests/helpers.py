@@ -26,7 +26,15 @@ def scene_by_name(name: str) -> WorldInfo:
         return scenarios.apartment_building(scenarios.load_vox_fixture(os.path.join(GOLDEN_DIR, "apartment_building_vox.npz")))
     if name == "Fast Oct Tree Sinnoh":
         return scenarios.sinnoh(*scenarios.load_map_fixture(os.path.join(GOLDEN_DIR, "sinnoh_map.npz")))
+    if name in ("Light Demonstration", "Easy Scene"):
+        return scenarios.build(name, earthmap())
     return scenarios.build(name)
+
+
+@functools.lru_cache(maxsize=None)
+def earthmap() -> np.ndarray:
+    """The reference's assets/earthmap.jpg, decoded (tests/golden/earthmap_rgb8.npz)."""
+    return scenarios.load_earthmap_fixture(os.path.join(GOLDEN_DIR, "earthmap_rgb8.npz"))
 
 
 def line_of_spheres(n: int, seed: int) -> WorldInfo:
