@@ -1,11 +1,13 @@
 // mrt_octree.cpp -- host-side construction of the linearised voxel octree (the step before the path
 // for voxel scenes). The reference builds FastOctTree<Voxel> by repeated `set` calls that split and
 // re-collapse nodes along one root-to-leaf path per voxel with node clones on the way
-// (fast_oct_tree/mod.rs:43-169, operations/set.rs:4-36); the tree it ends with is canonical: a node
+// (fast_oct_tree/mod.rs:43-169, operations/set.rs:4-36); the tree it ends with is canonical -- a node
 // whose eight children are equal leaves (or all empty) is that leaf (or empty), and the world edge is
-// the smallest power of two above the largest coordinate ever set. This builder keeps the voxel set
-// in a hash map (last write wins) and produces that canonical tree bottom-up from the Morton-sorted
-// set in O(n log n), then emits it in the layout of mrt_octree.
+// the smallest power of two above the largest coordinate ever set -- except for the chain of parents
+// with eight empty children that growing the world leaves in the origin corner (see the end of
+// mrt_voxels_linearise). This builder keeps the voxel set as a key-sorted array plus the sets made since (last write wins),
+// produces the canonical tree bottom-up from the sorted set -- one sort, then one linear pass per level --
+// adds that chain, and emits the result in the layout of mrt_octree.
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -17,8 +19,32 @@
 
 namespace {
 
-inline uint64_t pack(uint32_t x, uint32_t y, uint32_t z) { return ((uint64_t)x << 42) | ((uint64_t)y << 21) | (uint64_t)z; }
 constexpr uint32_t COORD_MAX = (1u << 21) - 1;
+
+// Cell key: the three 21-bit coordinates interleaved so that, per bit position b, the reference's child
+// index x*4 + y*2 + z (Node::pos_to_index, mod.rs:195-207) of bit b sits at bits 3b+2 .. 3b. Sorting by
+// this key puts the cells of every tree node next to each other at every level: parent = key >> 3,
+// child slot = key & 7.
+inline uint64_t spread21(uint32_t v) {
+    uint64_t x = v & 0x1FFFFFull;
+    x = (x | x << 32) & 0x1F00000000FFFFull;
+    x = (x | x << 16) & 0x1F0000FF0000FFull;
+    x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+inline uint32_t compact21(uint64_t x) {
+    x &= 0x1249249249249249ull;
+    x = (x ^ (x >> 2)) & 0x10C30C30C30C30C3ull;
+    x = (x ^ (x >> 4)) & 0x100F00F00F00F00Full;
+    x = (x ^ (x >> 8)) & 0x1F0000FF0000FFull;
+    x = (x ^ (x >> 16)) & 0x1F00000000FFFFull;
+    x = (x ^ (x >> 32)) & 0x1FFFFFull;
+    return (uint32_t)x;
+}
+inline uint64_t cell_key(uint32_t x, uint32_t y, uint32_t z) { return (spread21(x) << 2) | (spread21(y) << 1) | spread21(z); }
+inline void cell_xyz(uint64_t key, uint32_t& x, uint32_t& y, uint32_t& z) { x = compact21(key >> 2), y = compact21(key >> 1), z = compact21(key); }
 
 struct VoxelKey {  // exact-value identity of a voxel record
     unsigned char bytes[sizeof(mrt_voxel)];
@@ -32,10 +58,17 @@ struct VoxelKeyHash {
     }
 };
 
+struct Cell {
+    uint64_t key;
+    uint32_t voxel;  // index into mrt_voxel_grid::table
+};
+
 }  // namespace
 
+// The voxel set: `cells` is sorted by key with one entry per position; `pending` holds the sets made
+// since it was last brought up to date, in call order (a later set of a position overwrites).
 struct mrt_voxel_grid {
-    std::unordered_map<uint64_t, uint32_t> cells;  // packed position -> voxel record index
+    std::vector<Cell> cells, pending;
     std::vector<mrt_voxel> table;
     std::unordered_map<VoxelKey, uint32_t, VoxelKeyHash> table_index;
     int64_t max_coord = -1;  // largest coordinate ever set (also by voxels that were overwritten later)
@@ -59,8 +92,34 @@ struct mrt_voxel_grid {
         return id;
     }
     void set(uint32_t x, uint32_t y, uint32_t z, uint32_t voxel) {
-        cells[pack(x, y, z)] = voxel;
+        pending.push_back(Cell{cell_key(x, y, z), voxel});
         max_coord = std::max<int64_t>(max_coord, std::max(x, std::max(y, z)));
+    }
+    // Folds `pending` into `cells`: the last set of a position wins, also over what `cells` held.
+    void settle() {
+        if (pending.empty()) return;
+        std::stable_sort(pending.begin(), pending.end(), [](const Cell& a, const Cell& b) { return a.key < b.key; });
+        size_t n = 0;
+        for (size_t i = 0; i < pending.size(); ++i)
+            if (i + 1 == pending.size() || pending[i + 1].key != pending[i].key) pending[n++] = pending[i];
+        pending.resize(n);
+        if (cells.empty()) {
+            cells.swap(pending);
+        } else {
+            std::vector<Cell> merged;
+            merged.reserve(cells.size() + pending.size());
+            size_t a = 0, b = 0;
+            while (a < cells.size() || b < pending.size()) {
+                if (b == pending.size() || (a < cells.size() && cells[a].key < pending[b].key)) merged.push_back(cells[a++]);
+                else {
+                    if (a < cells.size() && cells[a].key == pending[b].key) ++a;
+                    merged.push_back(pending[b++]);
+                }
+            }
+            cells.swap(merged);
+        }
+        pending.clear();
+        pending.shrink_to_fit();
     }
 };
 
@@ -135,12 +194,22 @@ int mrt_voxels_combine(mrt_voxel_grid* dst, const mrt_voxel_grid* src, const int
     try {
         // combine.rs:4-19 sets other's voxels in x, y, z order; the order only matters between voxels of
         // `other`, which never collide with each other
-        for (const auto& kv : src->cells) {
-            int64_t x = (int64_t)(kv.first >> 42) + offset[0], y = (int64_t)((kv.first >> 21) & COORD_MAX) + offset[1],
-                    z = (int64_t)(kv.first & COORD_MAX) + offset[2];
+        std::vector<Cell> src_cells = src->cells, src_pending = src->pending;
+        if (!src_pending.empty()) {  // bring a private copy of the source up to date
+            mrt_voxel_grid tmp;
+            tmp.cells.swap(src_cells), tmp.pending.swap(src_pending);
+            tmp.settle();
+            src_cells.swap(tmp.cells);
+        }
+        std::vector<int64_t> remap(src->table.size(), -1);
+        for (const Cell& c : src_cells) {
+            uint32_t sx, sy, sz;
+            cell_xyz(c.key, sx, sy, sz);
+            int64_t x = (int64_t)sx + offset[0], y = (int64_t)sy + offset[1], z = (int64_t)sz + offset[2];
             if (x < 0 || y < 0 || z < 0) continue;  // positions that become negative are dropped
             if (x > COORD_MAX || y > COORD_MAX || z > COORD_MAX) return fail(MRT_ERR_INVALID_ARGUMENT, "voxel coordinate out of range");
-            dst->set((uint32_t)x, (uint32_t)y, (uint32_t)z, dst->intern(src->table[kv.second]));
+            if (remap[c.voxel] < 0) remap[c.voxel] = dst->intern(src->table[c.voxel]);
+            dst->set((uint32_t)x, (uint32_t)y, (uint32_t)z, (uint32_t)remap[c.voxel]);
         }
     } catch (const std::bad_alloc&) {
         return fail(MRT_ERR_OUT_OF_MEMORY, "out of host memory");
@@ -174,7 +243,15 @@ int mrt_voxels_load_vox(mrt_voxel_grid* g, const uint8_t* data, size_t len) {
     return MRT_OK;
 }
 
-size_t mrt_voxels_count(const mrt_voxel_grid* g) { return g ? g->cells.size() : 0; }
+size_t mrt_voxels_count(const mrt_voxel_grid* g) {
+    if (!g) return 0;
+    try {
+        const_cast<mrt_voxel_grid*>(g)->settle();  // representation only: the voxel set is unchanged
+    } catch (const std::bad_alloc&) {
+        return 0;
+    }
+    return g->cells.size();
+}
 
 int mrt_voxels_linearise(mrt_voxel_grid* g, mrt_octree* out) {
     if (!g || !out) return fail(MRT_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -182,56 +259,43 @@ int mrt_voxels_linearise(mrt_voxel_grid* g, mrt_octree* out) {
     try {
         uint32_t k = 0;
         while ((1ll << k) <= g->max_coord) ++k;  // world edge 2^k
+        g->settle();
         // compact the voxel table to the records that are still in use
         std::vector<int32_t> remap(g->table.size(), -1);
         g->used_voxels.clear();
-        struct Cell {
-            uint64_t key;      // packed position at the current level
+        struct Level {
+            uint64_t key;      // cell key at the current level
             int32_t kind;      // MRT_OCT_LEAF / MRT_OCT_PARENT
             int64_t payload;   // leaf: voxel id; parent: index of its first child record
         };
-        std::vector<Cell> cur;
+        std::vector<Level> cur, next;
         cur.reserve(g->cells.size());
-        for (const auto& kv : g->cells) {
-            if (remap[kv.second] < 0) {
-                remap[kv.second] = (int32_t)g->used_voxels.size();
-                g->used_voxels.push_back(g->table[kv.second]);
+        for (const Cell& c : g->cells) {
+            if (remap[c.voxel] < 0) {
+                remap[c.voxel] = (int32_t)g->used_voxels.size();
+                g->used_voxels.push_back(g->table[c.voxel]);
             }
-            cur.push_back(Cell{kv.first, MRT_OCT_LEAF, remap[kv.second]});
+            cur.push_back(Level{c.key, MRT_OCT_LEAF, remap[c.voxel]});
         }
-        // canonical order of the voxel table does not matter; order cells by position
-        std::sort(cur.begin(), cur.end(), [](const Cell& a, const Cell& b) { return a.key < b.key; });
         g->nodes.clear();
         g->children.clear();
-        auto parent_key = [](uint64_t key) {
-            uint32_t x = (uint32_t)(key >> 42), y = (uint32_t)((key >> 21) & COORD_MAX), z = (uint32_t)(key & COORD_MAX);
-            return pack(x >> 1, y >> 1, z >> 1);
-        };
-        auto slot_of = [](uint64_t key) {
-            uint32_t x = (uint32_t)(key >> 42), y = (uint32_t)((key >> 21) & COORD_MAX), z = (uint32_t)(key & COORD_MAX);
-            return ((x & 1u) << 2) | ((y & 1u) << 1) | (z & 1u);  // Node::pos_to_index, mod.rs: x*4 + y*2 + z
-        };
         for (uint32_t level = 1; level <= k; ++level) {
-            // cells of one parent are not contiguous in packed-position order: group by parent key
-            std::vector<std::pair<uint64_t, uint32_t>> order(cur.size());
-            for (uint32_t i = 0; i < cur.size(); ++i) order[i] = {parent_key(cur[i].key), i};
-            std::sort(order.begin(), order.end());
-            std::vector<Cell> next;
-            for (size_t b = 0; b < order.size();) {
+            // `cur` is sorted by key, so the cells of one parent (key >> 3) are consecutive
+            next.clear();
+            for (size_t b = 0; b < cur.size();) {
+                const uint64_t parent = cur[b].key >> 3;
                 size_t e = b;
-                while (e < order.size() && order[e].first == order[b].first) ++e;
                 int32_t ck[8];
                 int64_t cp[8];
                 for (int s = 0; s < 8; ++s) ck[s] = MRT_OCT_EMPTY, cp[s] = -1;
-                for (size_t i = b; i < e; ++i) {
-                    const Cell& c = cur[order[i].second];
-                    uint32_t s = slot_of(c.key);
-                    ck[s] = c.kind, cp[s] = c.payload;
+                for (; e < cur.size() && (cur[e].key >> 3) == parent; ++e) {
+                    const uint32_t s = (uint32_t)(cur[e].key & 7u);  // Node::pos_to_index: x*4 + y*2 + z
+                    ck[s] = cur[e].kind, cp[s] = cur[e].payload;
                 }
                 bool collapse = true;
                 for (int s = 0; s < 8; ++s) collapse = collapse && ck[s] == MRT_OCT_LEAF && cp[s] == cp[0];
                 if (collapse) {
-                    next.push_back(Cell{order[b].first, MRT_OCT_LEAF, cp[0]});
+                    next.push_back(Level{parent, MRT_OCT_LEAF, cp[0]});
                 } else {
                     int64_t first = (int64_t)g->children.size();
                     for (int s = 0; s < 8; ++s) {
@@ -242,7 +306,7 @@ int mrt_voxels_linearise(mrt_voxel_grid* g, mrt_octree* out) {
                         g->children.push_back((uint32_t)g->nodes.size());
                         g->nodes.push_back(rec);
                     }
-                    next.push_back(Cell{order[b].first, MRT_OCT_PARENT, first});
+                    next.push_back(Level{parent, MRT_OCT_PARENT, first});
                 }
                 b = e;
             }
@@ -255,6 +319,30 @@ int mrt_voxels_linearise(mrt_voxel_grid* g, mrt_octree* out) {
         root.voxel = cur[0].kind == MRT_OCT_LEAF ? (int32_t)cur[0].payload : -1;
         g->nodes.push_back(root);
         out->root = (uint32_t)g->nodes.size() - 1;
+        // The growth chain. `set` grows the world by wrapping the old root as child 0 of a new parent with
+        // seven empty siblings (operations/set.rs:11-30), starting from an empty root of size 0, and
+        // `set_child` re-collapses nodes only along the path of the voxel being set (mod.rs:129-165). So on the
+        // path root -> child 0 -> child 0 ... every node that holds no voxel is, in the reference's tree, a
+        // parent of eight empty children (down to size 1) where the canonical tree has one large empty node;
+        // rays through the origin corner step through those small cells.
+        for (uint32_t cur = out->root;;) {
+            if (g->nodes[cur].kind == MRT_OCT_PARENT) {
+                cur = g->children[(size_t)g->nodes[cur].first_child];
+                continue;
+            }
+            if (g->nodes[cur].kind != MRT_OCT_EMPTY || g->nodes[cur].size < 1) break;
+            const uint32_t child_size = g->nodes[cur].size - 1;
+            g->nodes[cur].kind = MRT_OCT_PARENT;
+            g->nodes[cur].first_child = (int32_t)g->children.size();
+            const uint32_t first = (uint32_t)g->nodes.size();
+            for (int s = 0; s < 8; ++s) {
+                mrt_oct_node rec{};
+                rec.kind = MRT_OCT_EMPTY, rec.size = child_size, rec.first_child = -1, rec.voxel = -1;
+                g->children.push_back(first + (uint32_t)s);
+                g->nodes.push_back(rec);
+            }
+            cur = first;
+        }
         out->n_nodes = (uint32_t)g->nodes.size();
         out->nodes = g->nodes.data();
         out->n_children = (uint32_t)g->children.size();

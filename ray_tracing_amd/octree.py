@@ -4,9 +4,10 @@ The reference builds `FastOctTree<Voxel>` by repeated `set` calls with leaf coll
 (cpu_rt/src/ray_tracer/hittable/fast_oct_tree/operations/set.rs:4-36, mod.rs:43-169) and loads
 MagicaVoxel files through dot_vox (operations/load.rs:74-127). Construction stays on the host; this
 module produces the same tree bottom-up from the final voxel set with numpy (a node whose eight
-children are equal leaves is one leaf, untouched regions are maximal empty nodes, the world edge is the
-smallest power of two above the largest coordinate ever set) and flattens it into the `mrt_octree`
-arrays. Only the query side (`trace_ray`, `ray_iteration`) runs on the GPU.
+children are equal leaves is one leaf, untouched regions are maximal empty nodes -- except the chain of
+small empty cells that growing the world leaves in the origin corner, `growth_spine` -- and the world
+edge is the smallest power of two above the largest coordinate ever set) and flattens it into the
+`mrt_octree` arrays. Only the query side (`trace_ray`, `ray_iteration`) runs on the GPU.
 """
 from __future__ import annotations
 
@@ -203,8 +204,33 @@ class OctTree:
         nodes["first_child"] = np.concatenate(out_fc)
         nodes["voxel"] = np.concatenate(out_vox)
         children = np.concatenate(children_blocks) if children_blocks else np.zeros(0, np.uint32)
-        return VoxelGrid(nodes=nodes, children=children.astype(np.uint32), voxels=voxel_table, root=n_nodes,
-                         records=records)
+        nodes, children = growth_spine(nodes, children.astype(np.uint32), n_nodes)
+        return VoxelGrid(nodes=nodes, children=children, voxels=voxel_table, root=n_nodes, records=records)
+
+
+def growth_spine(nodes: np.ndarray, children: np.ndarray, root: int):
+    """The one place where the tree the reference's `set` sequence ends with is not the canonical tree of the voxel
+    set. `set` grows the world by wrapping the old root as child 0 of a new parent with seven empty siblings
+    (operations/set.rs:11-30), starting from an empty root of size 0, and `set_child` re-collapses nodes only along
+    the path of the voxel being set (mod.rs:129-165). When the first voxel ever set is not at the origin, the wrapped
+    empty roots therefore stay behind as a chain of parents with eight empty children in the origin corner: on the
+    path root -> child 0 -> child 0 ..., every node that holds no voxel is a parent of eight empty children (down to
+    size 1) where the canonical tree has one large empty node. A ray through that corner steps through the small
+    empty cells. Appends those parents' children to (nodes, children); the root keeps its index."""
+    nodes, children = nodes.copy(), children.copy()
+    cur = root
+    while True:
+        kind, size = int(nodes[cur]["kind"]), int(nodes[cur]["size"])
+        if kind == F.OCT_PARENT:
+            cur = int(children[int(nodes[cur]["first_child"])])   # child 0
+            continue
+        if kind != F.OCT_EMPTY or size < 1:
+            return nodes, children
+        kids = np.zeros(8, dtype=NODE_DTYPE)
+        kids["kind"], kids["size"], kids["first_child"], kids["voxel"] = F.OCT_EMPTY, size - 1, -1, -1
+        nodes[cur]["kind"], nodes[cur]["first_child"] = F.OCT_PARENT, len(children)
+        children = np.concatenate([children, (len(nodes) + np.arange(8)).astype(np.uint32)])
+        nodes = np.concatenate([nodes, kids])
 
 
 # ------------------------------------------------------------------ MagicaVoxel .vox (dot_vox 5.1.1 semantics)
@@ -245,12 +271,13 @@ def parse_vox(data: bytes) -> VoxFile:
     return VoxFile(models, palette)
 
 
-def load_vox(vox: VoxFile) -> OctTree:
+def load_vox(vox: VoxFile, tree_cls=None):
     """FastOctTree::load_vox (operations/load.rs:74-127): all models overlaid, scene-graph transforms
-    ignored, x = vx - min_x, y = vz - min_z, z = (max_y - min_y) - (vy - min_y)."""
+    ignored, x = vx - min_x, y = vz - min_z, z = (max_y - min_y) - (vy - min_y). `tree_cls`: OctTree
+    (default) or NativeOctTree."""
     allv = np.concatenate(vox.models).astype(np.int64)
     mn, mx = allv[:, :3].min(axis=0), allv[:, :3].max(axis=0)
-    tree = OctTree()
+    tree = (tree_cls or OctTree)()
     for m in vox.models:
         v = m.astype(np.int64)
         pos = np.stack([v[:, 0] - mn[0], v[:, 2] - mn[2], -(v[:, 1] - mn[1]) + mx[1] - mn[1]], axis=1)
@@ -259,12 +286,12 @@ def load_vox(vox: VoxFile) -> OctTree:
     return tree
 
 
-def load_map(tiles, tile_size: int, models) -> OctTree:
+def load_map(tiles, tile_size: int, models, tree_cls=None):
     """FastOctTree::load_map (operations/load.rs:28-67): `tiles[x][z]` names a tile type; `models` maps a type to
     its VoxFile (types without a model are air). Tile (x, z) is combined at ((len - x - 1) * tile_size, 0,
     z * tile_size), in x-major order, later tiles overwriting earlier ones."""
-    trees = {k: load_vox(v) for k, v in models.items()}
-    tree = OctTree()
+    trees = {k: load_vox(v, tree_cls) for k, v in models.items()}
+    tree = (tree_cls or OctTree)()
     for x in range(len(tiles)):
         for z in range(len(tiles[x])):
             tile = trees.get(int(tiles[x][z]))
@@ -286,11 +313,11 @@ def box_points(start, end) -> np.ndarray:
     return g.astype(np.int64)
 
 
-def city_grid(building: OctTree) -> OctTree:
+def city_grid(building, tree_cls=None):
     """Geometry of `fast_oct_tree::city()` (cpu_rt/src/ray_tracer/world/fast_oct_tree.rs:818-883)."""
     ROAD_WIDTH, ROAD_LENGTH, LINE_POSITION, CELL_SIZE, NUMBER_GRIDS = 9, 400, 4, 64, 5
     line, road = from_color_hex("#e4af00"), from_color_hex("#363636")
-    grid = OctTree()
+    grid = (tree_cls or type(building))()
     for i in range(NUMBER_GRIDS):
         x_offset = i * (CELL_SIZE + ROAD_WIDTH)
         pts = box_points((x_offset, 0, 0), (ROAD_WIDTH + x_offset, 1, ROAD_LENGTH))

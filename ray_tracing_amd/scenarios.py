@@ -18,6 +18,23 @@ from .scene import (CameraInfo, CheckerTexture, ConstantColor, ConstantMedium, D
                     Sky, SolidColor, Sphere, SunSky, Transform, WorldInfo, XYRect, XZRect, YZRect)
 
 
+# Builder of the voxel octrees of the "Fast Oct Tree" scenarios: the library's C++ builder (`mrt_voxels_*`,
+# what a compiled host calls) unless `set_tree_builder("numpy")` selects the numpy one (the cross-check).
+_TREE_BUILDER = "native"
+
+
+def set_tree_builder(kind: str) -> None:
+    global _TREE_BUILDER
+    if kind not in ("native", "numpy"):
+        raise ValueError("tree builder must be 'native' or 'numpy'")
+    _TREE_BUILDER = kind
+
+
+def _tree_cls():
+    from .octree import NativeOctTree, OctTree
+    return NativeOctTree if _TREE_BUILDER == "native" else OctTree
+
+
 def _dist(a, b) -> float:
     t = [a[i] - b[i] for i in range(3)]
     return math.sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2])
@@ -176,7 +193,8 @@ def synthetic_earthmap(width: int = 256, height: int = 128) -> np.ndarray:
 
 def fast_oct_tree_sphere() -> WorldInfo:
     """world/fast_oct_tree.rs:13-62 ("Fast Oct Tree Sphere"): VoxelGrid::sphere(10) lit by a sphere light."""
-    from .octree import OctTree, box_points
+    from .octree import box_points
+    OctTree = _tree_cls()
     radius = 10
     pts = box_points((0, 0, 0), (2 * radius + 2,) * 3)
     centre = np.array([radius, radius, radius], dtype=np.float64)
@@ -210,8 +228,8 @@ def _volume_block(tree, voxel_row) -> None:
 
 def volume_two_density() -> WorldInfo:
     """world/fast_oct_tree.rs:322-407 ("Fast Oct Tree 2 density")."""
-    from .octree import OctTree, volume
-    tree = OctTree()
+    from .octree import volume
+    tree = _tree_cls()()
 
     def rows(pts):
         lo, hi = volume(0.3, (0.5, 0.05, 0.5)), volume(0.6, (0.5, 0.05, 0.5))
@@ -223,16 +241,16 @@ def volume_two_density() -> WorldInfo:
 
 def volume_lambertian() -> WorldInfo:
     """world/fast_oct_tree.rs:408-497 ("Fast Oct Tree Volume Lambertian")."""
-    from .octree import OctTree, solid_lambertian, volume
-    tree = OctTree()
+    from .octree import solid_lambertian, volume
+    tree = _tree_cls()()
     _volume_block(tree, volume(0.3, (0.5, 0.05, 0.5), 0.6, solid_lambertian((0.5, 0.05, 0.5))))
     return _volume_scene(tree, (50.0, 0.0, 20.0), 500.0, ConstantColor((0.1, 0.1, 0.1)))
 
 
 def volume_metal() -> WorldInfo:
     """world/fast_oct_tree.rs:498-594 ("Fast Oct Tree Volume Metal")."""
-    from .octree import OctTree, box_points, solid_lambertian, solid_reflect, volume
-    tree = OctTree()
+    from .octree import box_points, solid_lambertian, solid_reflect, volume
+    tree = _tree_cls()()
     _volume_block(tree, volume(0.3, (0.5, 0.05, 0.5), 0.6, solid_reflect((0.5, 0.05, 0.5), 0.3)))
     tree.set_rows(box_points((0, 0, 0), (40, 1, 40)), solid_lambertian((0.9, 0.9, 0.9)))
     return _volume_scene(tree, (0.0, 100.0, 200.0), 1000.0, ConstantColor((0.1, 0.1, 0.1)))
@@ -240,9 +258,9 @@ def volume_metal() -> WorldInfo:
 
 def volume_ice() -> WorldInfo:
     """world/fast_oct_tree.rs:595-690 ("Fast Oct Tree Volume Ice")."""
-    from .octree import OctTree, box_points, from_color_hex, solid_lambertian, solid_reflect, volume
+    from .octree import box_points, from_color_hex, solid_lambertian, solid_reflect, volume
     ice, snow = from_color_hex("#06068dff"), from_color_hex("#ffffffff")
-    tree = OctTree()
+    tree = _tree_cls()()
     pts = box_points((0, 1, 0), (10, 9, 10))
     snow_row = volume(0.001, snow, 1.0, solid_lambertian(snow))
     ice_row = volume(0.5, ice, 0.7, solid_reflect(ice, 0.1))
@@ -273,7 +291,7 @@ def voxel_city(building_vox, scale_roads: bool = True) -> WorldInfo:
     voxel_assets/city/skyscraper0.vox) with the camera and SunSky stored in examples/voxel_city_big.mscene
     (the .mscene itself holds no geometry; its loader sets sun = None and no lights, save_file.rs:108-131)."""
     from .octree import city_grid, load_vox
-    grid = city_grid(load_vox(building_vox))
+    grid = city_grid(load_vox(building_vox, _tree_cls()))
     bg = SunSky(intensity=0.05, sun_radius=0.08726646259971647, sun_theta=1.231, sun_phi=0.5235987755982988,
                 sun_brightness=22.0)
     cam = CameraInfo(1.0, 40.0, (-150.0, 200.0, -150.0), (512.0, 10.0, 512.0), (0.0, 1.0, 0.0), 1e-05,
@@ -285,13 +303,12 @@ def explosion() -> WorldInfo:
     """world/fast_oct_tree.rs:103-172 ("Fast Oct Tree Explosion"): a cosine height field of two colours under an
     orange sphere light. The heights are f32 arithmetic there; numpy's f32 cos may differ from Rust's in the last
     bit, which could move a column by one voxel where the height is within rounding of an integer."""
-    from .octree import OctTree
     xs, zs = np.meshgrid(np.arange(100), np.arange(100), indexing="ij")
     radius = np.sqrt((np.float32(50.0) - xs.astype(np.float32)) ** 2 + (np.float32(50.0) - zs.astype(np.float32)) ** 2,
                      dtype=np.float32)
     h = np.cos(radius / np.float32(10.0), dtype=np.float32) * np.float32(10.0) + np.float32(15.0)
     h = np.minimum(np.maximum(h, np.float32(0.0)), np.float32(19.0)).astype(np.int64)      # `as isize` truncates
-    tree = OctTree()
+    tree = _tree_cls()()
     cols = [(x, y, z) for x in range(100) for z in range(100) for y in range(int(h[x, z]) + 1)]
     pts = np.asarray(cols, dtype=np.int64)
     albedo = np.where((pts[:, 1] < 9)[:, None], np.float32([0.65, 0.8, 0.05])[None, :], np.float32([0.65, 0.05, 0.05])[None, :])
@@ -305,8 +322,8 @@ def explosion() -> WorldInfo:
 
 def cube_world() -> WorldInfo:
     """world/fast_oct_tree.rs:173-244 ("Fast Oct Tree Cubeworld"): a 3 x 3 x 3 block and three single voxels."""
-    from .octree import OctTree, box_points
-    tree = OctTree()
+    from .octree import box_points
+    tree = _tree_cls()()
     red = np.float32([0.65, 0.05, 0.05])
     tree.set_many(box_points((3, 3, 3), (6, 6, 6)), red)
     tree.set_many(np.asarray([(0, 0, 0), (0, 1, 0), (5, 5, 5)]), red)
@@ -316,11 +333,45 @@ def cube_world() -> WorldInfo:
                      CameraInfo(1.0, 40.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
 
 
+def volcano() -> WorldInfo:
+    """world/fast_oct_tree.rs:245-321 ("Fast Oct Tree Volcano"): every cell of a 1000^3 sweep inside a cone
+    (apex (500, 300, 500), radius 300 - y) and not inside the crater cone (apex (500, 125, 500), radius
+    (y - 125) / 0.3) unless below y = 150; cells inside both are lava (emissive-bright albedo #ffbb00 x 80), the
+    rest rock #5f1515. About 2.8e7 voxels, world 1024^3, lit by a sphere light that is also the light list.
+    The cone predicate is evaluated slice by slice in f64 exactly as the reference writes it."""
+    from .octree import from_color_hex, solid_lambertian
+    tree = _tree_cls()()
+    lava = solid_lambertian(tuple(np.float32(c) * np.float32(80.0) for c in np.float32(from_color_hex("#ffbb00"))))
+    rock = solid_lambertian(from_color_hex("#5f1515"))
+
+    def cone(px, py, pz, center, slope):
+        desired_radius = (py - center[1]) / slope
+        r2 = np.where(desired_radius > 0.0, desired_radius * desired_radius, 0.0)
+        return (px - center[0]) ** 2 + (pz - center[2]) ** 2 < r2
+
+    # the mountain's radius never exceeds 300 and it ends below y = 300: only that part of the sweep can be set
+    z0 = 200
+    py, pz = np.meshgrid(np.arange(300, dtype=np.float64), np.arange(z0, 801, dtype=np.float64), indexing="ij")
+    for x in range(200, 801):                  # IterBox order: x outermost (prelude.rs:57-77)
+        px = float(x)
+        mountain = cone(px, py, pz, (500.0, 300.0, 500.0), -1.0)
+        crater = cone(px, py, pz, (500.0, 125.0, 500.0), 0.3)
+        keep = mountain & (~crater | (py < 150.0))
+        for mask, row in ((keep & crater, lava), (keep & ~crater, rock)):
+            yy, zz = np.nonzero(mask)
+            if len(yy):
+                tree.set_rows(np.stack([np.full(len(yy), x), yy, zz + z0], axis=1), row)
+    origin, look_at = (1000.0, 500.0, -300.0), (500.0, 200.0, 500.0)
+    light = Object(Sphere(10.0, (-100.0, 50.0, -100.0), DiffuseLight(SolidColor((100.0, 100.0, 100.0)))))
+    return WorldInfo([Object(tree.linearise()), light], [Object(light.shape)], ConstantColor((0.1, 0.1, 0.1)),
+                     CameraInfo(1.0, 20.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
+
+
 def gold_cube() -> WorldInfo:
     """world/fast_oct_tree.rs:692-786 ("Fast Oct Tree Gold Cube"): three reflecting 16^3 cubes of fuzz 0.8, 0.4 and
     0.1 on a 128 x 128 floor."""
-    from .octree import OctTree, box_points, solid_lambertian, solid_reflect
-    tree = OctTree()
+    from .octree import box_points, solid_lambertian, solid_reflect
+    tree = _tree_cls()()
     tree.set_rows(box_points((0, 0, 0), (128, 1, 128)), solid_lambertian((0.8, 0.8, 0.8)))
     gold = (1.0, float(np.float32(254.0) / np.float32(255.0)), 0.0)
     for x, fuzz in [(30, 0.8), (60, 0.4), (90, 0.1)]:
@@ -336,7 +387,7 @@ def apartment_building(building_vox) -> WorldInfo:
     under Sky(0.4), no lights."""
     from .octree import load_vox
     origin, look_at = (-50.0, 100.0, -40.0), (30.0, 10.0, 30.0)
-    return WorldInfo([Object(load_vox(building_vox).linearise())], [], Sky(0.4),
+    return WorldInfo([Object(load_vox(building_vox, _tree_cls()).linearise())], [], Sky(0.4),
                      CameraInfo(1.0, 40.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
 
 
@@ -360,7 +411,7 @@ def sinnoh(tiles, tile_size: int, models) -> WorldInfo:
     under Sky(0.6), no lights."""
     from .octree import load_map
     origin, look_at = (-500.0, 300.0, 256.0), (256.0, 10.0, 256.0)
-    return WorldInfo([Object(load_map(tiles, tile_size, models).linearise())], [], Sky(0.6),
+    return WorldInfo([Object(load_map(tiles, tile_size, models, _tree_cls()).linearise())], [], Sky(0.6),
                      CameraInfo(1.0, 40.0, origin, look_at, (0.0, 1.0, 0.0), 0.00001, _dist(look_at, origin), 0.0, 0.0))
 
 
@@ -422,6 +473,7 @@ SCENARIOS: Dict[str, Callable[[], WorldInfo]] = {
     "Fast Oct Tree Cubeworld": cube_world,
     "Fast Oct Tree Gold Cube": gold_cube,
     "Fast Oct Tree Sphere": fast_oct_tree_sphere,
+    "Fast Oct Tree Volcano": volcano,
     "Cornell Smoke": cornell_smoke,
     "Easy Cornell Box": easy_cornell_box,
     "One Sphere": one_sphere,

@@ -26,7 +26,7 @@ SCENES = ["Cornell Smoke", "Random Scene", "Light Demonstration", "Easy Cornell 
           "Lambertian Demonstration", "Metallic Demonstration Smooth", "Metallic Demonstration Rough",
           "Dielectric Demonstration, Low Refraction", "Dielectric Demonstration, High Refraction", "Cube Field",
           "Fast Oct Tree Explosion", "Fast Oct Tree Cubeworld", "Fast Oct Tree Gold Cube",
-          "Fast Oct Tree Apartment Building", "Fast Oct Tree Sinnoh", "One Sphere"]
+          "Fast Oct Tree Apartment Building", "Fast Oct Tree Sinnoh", "One Sphere", "Fast Oct Tree Volcano"]
 
 
 def main(only=()):

@@ -382,9 +382,8 @@ def build_both(lib, coords, colors):
 
 def test_builder_matches_reference_construction_random(lib):
     rng = np.random.default_rng(3)
-    first = np.zeros((1, 3), np.int64)          # first voxel at the origin (see ray_tracing_amd/octree.py)
     for n, extent in [(1, 1), (8, 2), (50, 8), (400, 16), (3000, 40)]:
-        coords = np.concatenate([first, rng.integers(0, extent, size=(n, 3))])
+        coords = rng.integers(0, extent, size=(n, 3))
         colors = rng.integers(0, 3, size=(len(coords), 1)).astype(np.float32) * np.float32([0.25, 0.5, 1.0])
         a, b = build_both(lib, coords, colors)
         assert a == b
@@ -420,8 +419,7 @@ def test_vox_fixture_and_city_tree(lib):
     assert vg.nodes[vg.root]["size"] == 9
     # literal reference construction of the same voxels (roads in IterBox order, then the building)
     gc, gcol = grid.voxels()
-    a, bb = build_both(lib, np.concatenate([np.zeros((1, 3), np.int64), gc]),
-                       np.concatenate([gcol[(gc == 0).all(axis=1)], gcol]))
+    a, bb = build_both(lib, gc, gcol)
     assert a == bb
 
 
@@ -444,3 +442,24 @@ def test_load_map_places_tiles_mirrored_in_x(lib):
     assert got == {(2, 0, 0), (1, 0, 1), (0, 0, 0), (0, 0, 1)} and len(coords) == 4 * 8
     tiles, size, models = scenarios.load_map_fixture(os.path.join(GOLD, "sinnoh_map.npz"))
     assert tiles.shape == (26, 32) and size == 16 and sorted(models) == list(range(1, 11))
+
+
+def test_growth_chain_in_the_origin_corner(lib):
+    """`set` grows the world by wrapping the old root as child 0 of a new parent (operations/set.rs:11-30), starting
+    from an empty root of size 0, and only re-collapses along the path of the voxel it sets (mod.rs:129-165): when the
+    first voxel is not at the origin, the origin corner keeps a chain of parents with eight empty children. Both
+    builders reproduce the literal port's tree, chain included."""
+    a, b = build_both(lib, np.array([[5, 0, 0], [2, 0, 0]]), np.float32([[.1, .1, .1], [.2, .2, .2]]))
+    assert a == b
+    corner = a[2][0][2][0]                       # root (size 3) -> child 0 (size 2) -> child 0 (size 1)
+    assert corner == ("P", 1, (("E", 0),) * 8)
+    # a voxel at the origin later on replaces the chain's end by ordinary nodes
+    a, b = build_both(lib, np.array([[9, 9, 9], [0, 0, 0]]), np.float32([[.1, .1, .1], [.2, .2, .2]]))
+    assert a == b and a[2][0][2][0][2][0][2][0][0] == "L"
+    # sphere(10): the first voxel set is (0, 7, 8) (shapes/mod.rs:11-20)
+    pts = box_points((0, 0, 0), (22, 22, 22))
+    d = np.sqrt((((pts + 0.5) - 10.0) ** 2).sum(axis=1))
+    pts = pts[d <= 10]
+    assert pts[0].tolist() == [0, 7, 8]
+    a, b = build_both(lib, pts, np.broadcast_to(np.float32([0.5, 0.5, 0.5]), (len(pts), 3)))
+    assert a == b
