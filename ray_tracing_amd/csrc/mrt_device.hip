@@ -48,9 +48,6 @@ struct SceneView {
     int32_t n_cand_nodes;  // > 0: the per-lane query runs the candidate search instead of the walk
     int32_t n_cand_words;  // 32-node words of the candidate bit array in use
     const DCand4* cand_nodes;
-    const int32_t* cand_chain;
-    int32_t n_cand_depth;
-    int32_t pad_cand;
     const DObjRec* objects;  // one record per object (shape, transform, material)
     const DObjRec* lights;   // the light list, same record type
     const DTexture* textures;
@@ -926,19 +923,11 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
                     next = child;
                     continue;
                 }
-                // mark the leaf and its ancestors: one row of independent loads, LDS ORs that return nothing
-                const int4* row = reinterpret_cast<const int4*>(sv.cand_chain + (size_t)(-2 - child) * (size_t)sv.n_cand_depth);
-                for (int q = 0; q < sv.n_cand_depth / 4; ++q) {
-                    const int4 c = row[q];
-                    const int n4[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n4[e] >= 0) {
-                            (void)__hip_atomic_fetch_or(bits + (n4[e] >> 5) * lds.stride, 1u << (n4[e] & 31), __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-                            touched |= 1u << (n4[e] >> 5);
-                        }
-                }
+                // mark the leaf: an LDS OR that returns nothing
+                const int leaf = -2 - child;
+                (void)__hip_atomic_fetch_or(bits + (leaf >> 5) * lds.stride, 1u << (leaf & 31), __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+                touched |= 1u << (leaf >> 5);
             }
             if (next < 0) {
                 if (sp == 0) break;
@@ -966,7 +955,17 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
         m &= m - 1;
         return idx;
     };
-    int resume = 0;  // nodes below this index lie in a subtree whose box test failed
+    // The walk reaches a leaf iff the boxes of all its ancestors passed when the walk came to them. Those
+    // boxes are nested (an inner box is the union of its children's, bvh.rs:280-286) and the running bound
+    // only shrinks, and Aabb::hit is monotone in both: if the innermost ancestor -- the leaf's parent -- passes
+    // against the bound it met, every outer one passed against its own, larger bound. A leaf with a static
+    // box lies inside its parent's box and is tested later, so its own test implies the parent's too. That
+    // leaves one extra test: the parent of a leaf whose box depends on the query (MovingSphere, built into
+    // the parents at the shutter times only), once per parent, against the bound at the time the walk enters
+    // the parent -- which is the bound before the parent's first leaf, because the marked leaves come in
+    // pre-order.
+    int last_parent = -1;
+    bool last_parent_pass = true;
     int idx = next_marked();
     DNode nd{};
     if (idx >= 0) nd = sv.nodes[idx];
@@ -974,10 +973,24 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
         const int idx_next = next_marked();
         DNode nd_next{};
         if (idx_next >= 0) nd_next = sv.nodes[idx_next];
-        if (idx >= resume) {
-            STAMP_COUNT(st, nd.object >= 0 ? 2 : 1);
-            if (!lane_visit<FEAT>(sv, nd, ray, inv_d, g, w)) resume = nd.skip;
+        STAMP_COUNT(st, 2);
+        bool reach = true;
+        if constexpr ((FEAT & FEAT_SPHERE) != 0) {
+            if (nd.flags & NODE_DYNAMIC_BOX) {
+                if (nd.parent != last_parent) {
+                    last_parent = nd.parent;
+                    last_parent_pass = true;
+                    if (nd.parent >= 0) {
+                        STAMP_COUNT(st, 1);
+                        const DNode pn = sv.nodes[nd.parent];
+                        last_parent_pass = aabb_hit(D3{pn.bmin[0], pn.bmin[1], pn.bmin[2]}, D3{pn.bmax[0], pn.bmax[1], pn.bmax[2]}, ray,
+                                                    inv_d, (double)0.001f, w.closest);
+                    }
+                }
+                reach = last_parent_pass;
+            }
         }
+        if (reach) (void)lane_visit<FEAT>(sv, nd, ray, inv_d, g, w);
         idx = idx_next;
         nd = nd_next;
     }
@@ -2313,7 +2326,7 @@ int upload_scene(mrt_scene* sc) {
     UP(f.nodes, nodes)
     if ((rc = m.upload(f.node_recs, &sc->dev_node_recs)) != MRT_OK) return rc;
     if ((rc = m.upload(f.leaf_recs, &sc->dev_leaf_recs)) != MRT_OK) return rc;
-    UP(f.cand_nodes, cand_nodes) UP(f.cand_chain, cand_chain)
+    UP(f.cand_nodes, cand_nodes)
     UP(f.obj_recs, objects) UP(f.light_recs, lights)
     UP(f.textures, textures) UP(f.images, images) UP(f.image_pool, image_pool) UP(f.perlins, perlins)
     UP(f.octrees, octrees) UP(f.oct_nodes, oct_nodes) UP(f.oct_voxels, oct_voxels)
@@ -2321,7 +2334,6 @@ int upload_scene(mrt_scene* sc) {
     v.n_nodes = (int32_t)f.node_object.size();
     v.n_cand_nodes = (int32_t)f.cand_nodes.size();
     v.n_cand_words = f.cand_nodes.empty() ? 0 : (int32_t)((f.node_object.size() + 31) / 32);
-    v.n_cand_depth = f.cand_depth;
     v.n_objects = (int32_t)f.objects.size();
     v.n_lights = (int32_t)f.lights.size();
     v.cam = f.camera;

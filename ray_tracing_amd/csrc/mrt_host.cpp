@@ -453,7 +453,6 @@ int collapse(const std::vector<Cand2>& b2, int i, std::vector<DCand4>* out, int*
 void build_candidate_tree(FlatScene* s) {
     if (s->nodes.size() > (size_t)CAND_MAX_NODES) return;
     std::vector<CandItem> items;
-    std::vector<int32_t> leaf_order;  // row -> index of the leaf in `nodes`
     for (size_t i = 0; i < s->nodes.size(); ++i) {
         const DNode& nd = s->nodes[i];
         if (nd.object < 0) continue;
@@ -461,8 +460,7 @@ void build_candidate_tree(FlatScene* s) {
         if ((nd.flags & NODE_TWICE) || shape_is_stochastic(*s, ob.shape)) return;
         CandItem it;
         if (!tight_box(*s, ob, &it)) return;
-        it.node = (int32_t)leaf_order.size();  // row of the ancestor table
-        leaf_order.push_back((int32_t)i);
+        it.node = (int32_t)i;  // index of the leaf in `nodes`
         items.push_back(it);
     }
     if (items.empty()) return;
@@ -480,26 +478,6 @@ void build_candidate_tree(FlatScene* s) {
     if (need > CAND_STACK || s->cand_nodes.size() > 65535) {
         s->cand_nodes.clear();
         return;
-    }
-    // ancestor rows: parents in the pre-order node array (a node's subtree ends at its skip link)
-    std::vector<int32_t> parent(s->nodes.size(), -1), open;
-    for (size_t i = 0; i < s->nodes.size(); ++i) {
-        while (!open.empty() && s->nodes[(size_t)open.back()].skip <= (int32_t)i) open.pop_back();
-        parent[i] = open.empty() ? -1 : open.back();
-        if (s->nodes[i].object < 0) open.push_back((int32_t)i);
-    }
-    int depth = 0;
-    for (int32_t leaf : leaf_order) {
-        int d = 0;
-        for (int32_t n = leaf; n >= 0; n = parent[(size_t)n]) ++d;
-        depth = std::max(depth, d);
-    }
-    depth = (depth + 3) / 4 * 4;  // rows are read four entries at a time
-    s->cand_depth = depth;
-    s->cand_chain.assign(leaf_order.size() * (size_t)depth, -1);
-    for (size_t row = 0; row < leaf_order.size(); ++row) {
-        size_t k = row * (size_t)depth;
-        for (int32_t n = leaf_order[row]; n >= 0; n = parent[(size_t)n]) s->cand_chain[k++] = n;
     }
 }
 
@@ -801,7 +779,16 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
         for (size_t i = 0; i < s.nodes.size(); ++i) {
             DNode& nd = s.nodes[i];
             for (int a = 0; a < 3; ++a) nd.bmin[a] = s.bmin[a][i], nd.bmax[a] = s.bmax[a][i];
-            nd.object = s.node_object[i], nd.skip = s.node_skip[i], nd.flags = s.node_flags[i], nd.pad = 0;
+            nd.object = s.node_object[i], nd.skip = s.node_skip[i], nd.flags = s.node_flags[i], nd.parent = -1;
+        }
+        {
+            // parents in the pre-order array (a node's subtree ends at its skip link)
+            std::vector<int32_t> open;
+            for (size_t i = 0; i < s.nodes.size(); ++i) {
+                while (!open.empty() && s.nodes[(size_t)open.back()].skip <= (int32_t)i) open.pop_back();
+                s.nodes[i].parent = open.empty() ? -1 : open.back();
+                if (s.nodes[i].object < 0) open.push_back((int32_t)i);
+            }
         }
         // self-contained node records for the wave-synchronous walk
         s.node_recs.resize(s.node_object.size());

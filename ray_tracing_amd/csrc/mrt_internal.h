@@ -92,7 +92,7 @@ struct DNode {
     int32_t object;  // >= 0 leaf, -1 inner
     int32_t skip;    // next node in pre-order when this subtree is left
     int32_t flags;   // NODE_*
-    int32_t pad;
+    int32_t parent;  // index of the enclosing inner node, -1 for the root
 };
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
 
@@ -103,7 +103,7 @@ static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
 // to hold for every tau. The velocity bounds are stored twice, indexed by the sign of tau, which
 // turns the min/max of the interval product into one fma per corner.
 struct DCand4 {
-    int32_t child[4];  // >= 0: node index; -1: none; <= -2: leaf, row (-2 - child) of FlatScene::cand_chain
+    int32_t child[4];  // >= 0: node index; -1: none; <= -2: leaf, index (-2 - child) in FlatScene::nodes
     int32_t moving;    // 0: every velocity bound is 0
     int32_t pad[3];
     double lo[3][4], hi[3][4];
@@ -186,11 +186,8 @@ struct FlatScene {
     std::vector<DNodeRec> leaf_recs;
     std::vector<DObjRec> obj_recs, light_recs;
     // Candidate search for large trees (see build_candidate_tree): a spatial tree over tight boxes of
-    // the leaves of `nodes`, and per leaf one row of cand_depth entries of cand_chain holding the
-    // leaf's index in `nodes` and those of its ancestors (-1 padded). Empty when the scene does not qualify.
+    // the leaves of `nodes`. Empty when the scene does not qualify.
     std::vector<DCand4> cand_nodes;
-    std::vector<int32_t> cand_chain;
-    int32_t cand_depth = 0;
     bool has_medium = false;
 };
 

@@ -93,35 +93,35 @@ int main() {
             continue;
         }
         if (f.cand_nodes.empty()) return fail("no candidate tree", scene);
-        // every leaf of the tree appears exactly once among the candidate tree's leaves, and its row
-        // of the ancestor table is the chain leaf -> root
-        int leaves = 0;
-        for (int i = 0; i < nn; ++i) leaves += f.nodes[i].object >= 0;
-        std::vector<int> seen((size_t)leaves, 0);
+        // every leaf of the tree appears exactly once among the candidate tree's leaves, and every node's
+        // parent link names the inner node whose subtree holds it
+        std::vector<int> seen((size_t)nn, 0);
         for (const mrt::DCand4& c : f.cand_nodes) {
             for (int k = 0; k < 4; ++k) {
                 const int ch = c.child[k];
                 if (ch >= 0 && ch >= (int)f.cand_nodes.size()) return fail("child index", scene);
                 if (ch <= -2) {
-                    const int row = -2 - ch;
-                    if (row >= leaves || seen[(size_t)row]++) return fail("leaf row", scene);
+                    const int leaf = -2 - ch;
+                    if (leaf >= nn || f.nodes[leaf].object < 0 || seen[(size_t)leaf]++) return fail("leaf index", scene);
                     for (int a = 0; a < 3; ++a)
                         if (!(c.lo[a][k] <= c.hi[a][k])) return fail("leaf box", scene);
                 }
             }
         }
-        for (int r = 0; r < leaves; ++r) {
-            if (!seen[(size_t)r]) return fail("leaf missing from the candidate tree", scene);
-            const int32_t* row = f.cand_chain.data() + (size_t)r * (size_t)f.cand_depth;
-            if (row[0] < 0 || row[0] >= nn || f.nodes[row[0]].object < 0) return fail("row does not start at a leaf", scene);
-            int k = 1;
-            for (; k < f.cand_depth && row[k] >= 0; ++k) {
-                const mrt::DNode& a = f.nodes[row[k]];
-                if (a.object >= 0 || !(row[k] < row[k - 1] && row[k - 1] < a.skip)) return fail("ancestor chain", scene);
+        for (int i = 0; i < nn; ++i) {
+            const mrt::DNode& nd = f.nodes[i];
+            if (nd.object >= 0 && !seen[(size_t)i]) return fail("leaf missing from the candidate tree", scene);
+            if (i == 0) {
+                if (nd.parent != -1) return fail("root has a parent", scene);
+                continue;
             }
-            if (row[k - 1] != 0 && nn > 1) return fail("chain does not reach the root", scene);
-            for (; k < f.cand_depth; ++k)
-                if (row[k] != -1) return fail("row padding", scene);
+            if (nd.parent < 0 || nd.parent >= i) return fail("parent link", scene);
+            const mrt::DNode& p = f.nodes[nd.parent];
+            if (p.object >= 0 || !(i < p.skip)) return fail("parent does not enclose the node", scene);
+            for (int j = nd.parent + 1; j < i; ++j)   // no closer enclosing inner node
+                if (f.nodes[j].object < 0 && i < f.nodes[j].skip) return fail("parent is not the innermost", scene);
+            for (int a = 0; a < 3; ++a)               // inner boxes are nested
+                if (nd.object < 0 && !(p.bmin[a] <= nd.bmin[a] && nd.bmax[a] <= p.bmax[a])) return fail("boxes not nested", scene);
         }
     }
     std::puts("host flattening: 40 scenes ok");
