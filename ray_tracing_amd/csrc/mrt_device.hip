@@ -271,19 +271,25 @@ __device__ __forceinline__ const CONST_AS T* as_const(const T* p) {
 }
 
 // ============================================================== transforms (hittable.rs:92-107)
+// The functions of the nearest-hit query below (transforms, shape and box tests) spell out their
+// fused multiply-adds and switch the compiler's own contraction off: the same source then rounds the
+// same way in every instantiation (scalar or per-lane operands, any feature set), which is what lets the
+// traversal variants be compared bit for bit.
 template <class AP>
 __device__ __forceinline__ D3 apply(AP a, D3 p) {
-    return {((a->r[0][0] * p.x + a->r[0][1] * p.y) + a->r[0][2] * p.z) + a->r[0][3],
-            ((a->r[1][0] * p.x + a->r[1][1] * p.y) + a->r[1][2] * p.z) + a->r[1][3],
-            ((a->r[2][0] * p.x + a->r[2][1] * p.y) + a->r[2][2] * p.z) + a->r[2][3]};
+#pragma clang fp contract(off)
+    return {fma(a->r[0][2], p.z, fma(a->r[0][1], p.y, a->r[0][0] * p.x)) + a->r[0][3],
+            fma(a->r[1][2], p.z, fma(a->r[1][1], p.y, a->r[1][0] * p.x)) + a->r[1][3],
+            fma(a->r[2][2], p.z, fma(a->r[2][1], p.y, a->r[2][0] * p.x)) + a->r[2][3]};
 }
 // Transform::mul_ray: direction = M*(o+d) - M*o; never renormalised, so t is shared.
 template <class AP>
 __device__ __forceinline__ RayD xform_ray(AP a, bool identity, const RayD& r) {
-    if (identity) return {r.o, (r.o + r.d) - r.o, r.time};
-    D3 e = apply(a, r.o + r.d);
+#pragma clang fp contract(off)
+    if (identity) return {r.o, D3{(r.o.x + r.d.x) - r.o.x, (r.o.y + r.d.y) - r.o.y, (r.o.z + r.d.z) - r.o.z}, r.time};
+    D3 e = apply(a, D3{r.o.x + r.d.x, r.o.y + r.d.y, r.o.z + r.d.z});
     D3 o = apply(a, r.o);
-    return {o, e - o, r.time};
+    return {o, D3{e.x - o.x, e.y - o.y, e.z - o.z}, r.time};
 }
 
 // ============================================================== shape intersection
@@ -292,12 +298,13 @@ __device__ __forceinline__ RayD xform_ray(AP a, bool identity, const RayD& r) {
 template <int AXIS>
 __device__ __forceinline__ bool rect_hit(double a0, double a1, double b0, double b1, double k, const RayD& r, D3 inv,
                                          double t_min, double t_max, double& t_out) {
+#pragma clang fp contract(off)
     constexpr int IA = AXIS == 0 ? 1 : 0;
     constexpr int IB = AXIS == 2 ? 1 : 2;
     double t = (k - comp(r.o, AXIS)) * comp(inv, AXIS);
     if (t < t_min || t > t_max) return false;
-    double a = comp(r.o, IA) + t * comp(r.d, IA);
-    double b = comp(r.o, IB) + t * comp(r.d, IB);
+    double a = fma(t, comp(r.d, IA), comp(r.o, IA));
+    double b = fma(t, comp(r.d, IB), comp(r.o, IB));
     if (a < a0 || a > a1 || b < b0 || b > b1) return false;
     t_out = t;
     return true;
@@ -305,11 +312,12 @@ __device__ __forceinline__ bool rect_hit(double a0, double a1, double b0, double
 // sphere.rs:28-45 (also MovingSphere :145-162 with center(time))
 __device__ __forceinline__ bool sphere_hit(D3 c, double radius, const RayD& r, double t_min, double t_max,
                                            double& t_out) {
-    D3 rel = r.o - c;
-    double a = dot(r.d, r.d);
-    double half_b = dot(rel, r.d);
-    double cc = dot(rel, rel) - radius * radius;
-    double disc = half_b * half_b - a * cc;
+#pragma clang fp contract(off)
+    const double rx = r.o.x - c.x, ry = r.o.y - c.y, rz = r.o.z - c.z;
+    double a = fma(r.d.z, r.d.z, fma(r.d.y, r.d.y, r.d.x * r.d.x));
+    double half_b = fma(rz, r.d.z, fma(ry, r.d.y, rx * r.d.x));
+    double cc = fma(-radius, radius, fma(rz, rz, fma(ry, ry, rx * rx)));
+    double disc = fma(-a, cc, half_b * half_b);
     if (disc < 0.0) return false;
     double sq = sqrt(disc);
     double inv_a = rcp_fast(a);
@@ -324,8 +332,9 @@ __device__ __forceinline__ bool sphere_hit(D3 c, double radius, const RayD& r, d
 // sphere.rs:139-142
 template <class PP>
 __device__ __forceinline__ D3 moving_center(PP p, double time) {
+#pragma clang fp contract(off)
     double f = (time - p[7]) / (p[8] - p[7]);
-    return D3{p[1], p[2], p[3]} + f * (D3{p[4], p[5], p[6]} - D3{p[1], p[2], p[3]});
+    return D3{fma(f, p[4] - p[1], p[1]), fma(f, p[5] - p[2], p[2]), fma(f, p[6] - p[3], p[3])};
 }
 // render_box.rs:117-129: faces in order xy+, xy-, xz+, xz-, yz+, yz-; strictly smaller t replaces.
 template <class PP>
@@ -352,15 +361,17 @@ __device__ __forceinline__ bool box_hit(PP p, const RayD& r, D3 inv, double t_mi
 template <int AXIS>
 __device__ __forceinline__ void rect_plane(double a0, double a1, double b0, double b1, double k, const RayD& r, D3 inv,
                                            double& t, bool& inside) {
+#pragma clang fp contract(off)
     constexpr int IA = AXIS == 0 ? 1 : 0;
     constexpr int IB = AXIS == 2 ? 1 : 2;
     t = (k - comp(r.o, AXIS)) * comp(inv, AXIS);
-    double a = comp(r.o, IA) + t * comp(r.d, IA);
-    double b = comp(r.o, IB) + t * comp(r.d, IB);
+    double a = fma(t, comp(r.d, IA), comp(r.o, IA));
+    double b = fma(t, comp(r.d, IB), comp(r.o, IB));
     inside = !(a < a0 || a > a1 || b < b0 || b > b1);
 }
 template <class PP>
 __device__ __forceinline__ bool box_hit_twice(PP p, const RayD& r, D3 inv, double& t1, double& t2) {
+#pragma clang fp contract(off)
     double tf[6];
     bool in[6];
     rect_plane<2>(p[0], p[3], p[1], p[4], p[5], r, inv, tf[0], in[0]);
@@ -410,6 +421,7 @@ __device__ __forceinline__ bool solid_hit_kp(int kind, PP p, const RayD& r, D3 i
 
 // Aabb::hit (bvh.rs:18-33): every axis is tested on its own against the ORIGINAL [t_min, t_max].
 __device__ __forceinline__ bool aabb_hit(D3 mn, D3 mx, const RayD& r, D3 inv_d, double t_min, double t_max) {
+#pragma clang fp contract(off)
     {
         double t0 = (mn.x - r.o.x) * inv_d.x, t1 = (mx.x - r.o.x) * inv_d.x;
         if (inv_d.x < 0.0) { double s = t0; t0 = t1; t1 = s; }
@@ -722,6 +734,7 @@ __device__ __forceinline__ bool leaf_hit(const SceneView& sv, int kind, int bkin
                                          double neg_inv_density, bool identity, AP to_object, const RayD& ray,
                                          D3 inv_world, double t_min, double t_max, const Rng& g, uint32_t medium_dim,
                                          uint32_t& oct_entry, double& t, int& sub, D3& pos) {
+#pragma clang fp contract(off)
     RayD sr = ray;
     D3 inv = inv_world;
     if (!identity) {
@@ -765,12 +778,12 @@ __device__ __forceinline__ bool leaf_hit(const SceneView& sv, int kind, int bkin
         if (t2 > t_max) t2 = t_max;
         if (t1 >= t2) return false;
         if (t1 < 0.0) t1 = 0.0;
-        double len2 = sr.d.x * sr.d.x + sr.d.y * sr.d.y + sr.d.z * sr.d.z;
+        double len2 = fma(sr.d.z, sr.d.z, fma(sr.d.y, sr.d.y, sr.d.x * sr.d.x));
         double ray_length = sqrt(len2);
         double distance_inside = (t2 - t1) * ray_length;
-        double hit_distance = neg_inv_density * log(rand_scalar(g, 0.0, 1.0, medium_dim));
+        double hit_distance = neg_inv_density * log(rng_f64(g, medium_dim));  // rand_scalar(0, 1) is the uniform itself
         if (hit_distance > distance_inside) return false;
-        t = t1 + hit_distance * rcp_fast(ray_length);
+        t = fma(hit_distance, rcp_fast(ray_length), t1);
         return true;
     }
     return false;
@@ -794,15 +807,17 @@ __device__ __forceinline__ bool node_hit(const SceneView& sv, RP r, const RayD& 
 
 // Leaf box of a MovingSphere-based object for the time window (t0, t1) the reference passes
 // (bvh.rs:142-145,180; sphere.rs:175-186; hittable.rs:239-282).
-template <class OP>
-__device__ void dynamic_leaf_box(OP ob, double t0, double t1, D3& mn, D3& mx) {
-    auto p = ob->p;
+template <class OP, class PP>
+__device__ void dynamic_leaf_box(OP ob, PP p, bool identity, double t0, double t1, D3& mn, D3& mx) {
+#pragma clang fp contract(off)
     D3 c0 = moving_center(p, t0), c1 = moving_center(p, t1);
     D3 r{p[0], p[0], p[0]};
-    D3 lo0 = c0 - r, hi0 = c0 + r, lo1 = c1 - r, hi1 = c1 + r;
+    D3 lo0{c0.x - r.x, c0.y - r.y, c0.z - r.z}, hi0{c0.x + r.x, c0.y + r.y, c0.z + r.z};
+    D3 lo1{c1.x - r.x, c1.y - r.y, c1.z - r.z}, hi1{c1.x + r.x, c1.y + r.y, c1.z + r.z};
     D3 smn{lo0.x < lo1.x ? lo0.x : lo1.x, lo0.y < lo1.y ? lo0.y : lo1.y, lo0.z < lo1.z ? lo0.z : lo1.z};
     D3 smx{hi0.x > hi1.x ? hi0.x : hi1.x, hi0.y > hi1.y ? hi0.y : hi1.y, hi0.z > hi1.z ? hi0.z : hi1.z};
-    D3 a = apply(&ob->to_world, smn), b = apply(&ob->to_world, smx);
+    // (the identity matrix maps a finite corner to itself exactly)
+    D3 a = identity ? smn : apply(&ob->to_world, smn), b = identity ? smx : apply(&ob->to_world, smx);
     mn = {a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y, a.z < b.z ? a.z : b.z};
     mx = {a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y, a.z > b.z ? a.z : b.z};
 }
@@ -838,21 +853,36 @@ __device__ __forceinline__ bool lane_visit(const SceneView& sv, const DNode& nd,
     const int flags = nd.flags;
     D3 mn{nd.bmin[0], nd.bmin[1], nd.bmin[2]};
     D3 mx{nd.bmax[0], nd.bmax[1], nd.bmax[2]};
+    // A leaf's record head (kinds, identity flag) and shape parameters are requested together, before the
+    // box test decides whether they are needed: the loads are independent of each other, and a lane's walk
+    // is a chain of dependent fetches that every load issued later, inside a branch, would lengthen.
+    const DObjRec* ob = sv.objects + (obj >= 0 ? obj : 0);
+    int4 head{0, 0, 0, 0};
+    double p[10];
+    if (obj >= 0) {
+        head = *reinterpret_cast<const int4*>(&ob->kind);  // kind, gkind, identity, octree
+#pragma unroll
+        for (int i = 0; i < 10; i += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(&ob->p[i]);
+            p[i] = v.x, p[i + 1] = v.y;
+        }
+    }
+    const bool identity = head.z != 0;
     if constexpr ((FEAT & FEAT_SPHERE) != 0) {
-        if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(sv.objects + obj, t_min, w.closest, mn, mx);
+        if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(ob, p, identity, t_min, w.closest, mn, mx);
     }
     if (!aabb_hit(mn, mx, ray, inv_d, t_min, w.closest)) return false;
     if (obj >= 0) {
-        const DObjRec* ob = sv.objects + obj;
         bool is_medium = false;
-        if constexpr ((FEAT & FEAT_MEDIUM) != 0) is_medium = ob->kind == MRT_SHAPE_CONSTANT_MEDIUM;
+        if constexpr ((FEAT & FEAT_MEDIUM) != 0) is_medium = head.x == MRT_SHAPE_CONSTANT_MEDIUM;
         const int rounds = (flags & NODE_TWICE) ? 2 : 1;
 #pragma nounroll
         for (int round = 0; round < rounds; ++round) {
             if (round == 1 && !aabb_hit(mn, mx, ray, inv_d, t_min, w.closest)) break;
             double t;
             int sub;
-            if (object_hit<FEAT>(sv, ob, ray, inv_d, t_min, w.closest, g, MRT_DIM_MEDIUM + w.medium_ordinal, w.oct_entry, t, sub, w.best_pos)) {
+            if (leaf_hit<FEAT>(sv, head.x, head.y, head.w, p, p[9], identity, &ob->to_object, ray, inv_d, t_min, w.closest, g,
+                               MRT_DIM_MEDIUM + w.medium_ordinal, w.oct_entry, t, sub, w.best_pos)) {
                 w.closest = t, w.best_obj = obj, w.best_sub = sub;
             }
             if (is_medium) w.medium_ordinal++;
@@ -866,22 +896,6 @@ struct CandRay {
     double tau;
     int neg;  // tau < 0: selects the velocity bounds that give the lower / upper corner
 };
-// Whether the ray's line over [0.001, FLT_MAX] can meet the box of child k at the ray's time (all
-// three slabs jointly). Rays with a zero or non-finite direction component never get here.
-__device__ __forceinline__ bool line_meets_child(const DCand4* nd, int k, bool moving, const CandRay& r) {
-    double lo = (double)0.001f, hi = (double)FLT_MAX;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        double bl = nd->lo[a][k], bh = nd->hi[a][k];
-        if (moving) {
-            bl = fma(r.tau, nd->v_for_lo[r.neg][a][k], bl);
-            bh = fma(r.tau, nd->v_for_hi[r.neg][a][k], bh);
-        }
-        const double t0 = fma(bl, r.inv[a], -r.oi[a]), t1 = fma(bh, r.inv[a], -r.oi[a]);
-        lo = fmax(lo, fmin(t0, t1)), hi = fmin(hi, fmax(t0, t1));
-    }
-    return lo <= hi;
-}
 #define LDS_AS __attribute__((address_space(3)))
 // Per-lane LDS state of the candidate search: a [CAND_WORDS][BLOCK] bit array, one bit per tree
 // node, all zero between queries, and a [CAND_STACK][BLOCK] node stack (columns of this lane).
@@ -908,23 +922,71 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
         int sp = 0;
         int node = 0;
         for (;;) {
+            // One node = one batch of independent loads (the whole first line, then the velocity line of a
+            // node with moving children), requested before anything is tested: a lane's walk is a chain of
+            // dependent node fetches, and a load issued inside a per-child branch would add its own
+            // round trip to that chain.
             const DCand4* nd = sv.cand_nodes + node;
+            const int4 ch4 = *reinterpret_cast<const int4*>(nd->child);
+            float4 lo4[3], hi4[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                lo4[a] = *reinterpret_cast<const float4*>(nd->lo[a]);
+                hi4[a] = *reinterpret_cast<const float4*>(nd->hi[a]);
+            }
             const bool moving = nd->moving != 0;
             STAMP_COUNT(st, 0);
+            double bl[3][4], bh[3][4];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                bl[a][0] = (double)lo4[a].x, bl[a][1] = (double)lo4[a].y, bl[a][2] = (double)lo4[a].z, bl[a][3] = (double)lo4[a].w;
+                bh[a][0] = (double)hi4[a].x, bh[a][1] = (double)hi4[a].y, bh[a][2] = (double)hi4[a].z, bh[a][3] = (double)hi4[a].w;
+            }
+            if (moving) {
+                // tau >= 0: the lower corner moves with the smallest velocity, the upper with the largest; tau < 0: swapped
+                const float(*v_for_lo)[4] = cr.neg ? nd->vhi : nd->vlo;
+                const float(*v_for_hi)[4] = cr.neg ? nd->vlo : nd->vhi;
+                float4 vl4[3], vh4[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    vl4[a] = *reinterpret_cast<const float4*>(v_for_lo[a]);
+                    vh4[a] = *reinterpret_cast<const float4*>(v_for_hi[a]);
+                }
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    bl[a][0] = fma(cr.tau, (double)vl4[a].x, bl[a][0]), bl[a][1] = fma(cr.tau, (double)vl4[a].y, bl[a][1]);
+                    bl[a][2] = fma(cr.tau, (double)vl4[a].z, bl[a][2]), bl[a][3] = fma(cr.tau, (double)vl4[a].w, bl[a][3]);
+                    bh[a][0] = fma(cr.tau, (double)vh4[a].x, bh[a][0]), bh[a][1] = fma(cr.tau, (double)vh4[a].y, bh[a][1]);
+                    bh[a][2] = fma(cr.tau, (double)vh4[a].z, bh[a][2]), bh[a][3] = fma(cr.tau, (double)vh4[a].w, bh[a][3]);
+                }
+            }
+            const int child[4] = {ch4.x, ch4.y, ch4.z, ch4.w};
+            bool meets[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // whether the ray's line over [0.001, FLT_MAX] can meet the box of child k at the ray's time (all
+                // three slabs jointly); an absent child has an inside-out box (lo = inf, hi = -inf) and never passes
+                double lo = (double)0.001f, hi = (double)FLT_MAX;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double t0 = fma(bl[a][k], cr.inv[a], -cr.oi[a]), t1 = fma(bh[a][k], cr.inv[a], -cr.oi[a]);
+                    lo = fmax(lo, fmin(t0, t1)), hi = fmin(hi, fmax(t0, t1));
+                }
+                meets[k] = lo <= hi && child[k] != -1;
+            }
             int next = -1;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int child = nd->child[k];
-                if (child == -1 || !line_meets_child(nd, k, moving, cr)) continue;
-                if (child >= 0) {
+                if (!meets[k]) continue;
+                if (child[k] >= 0) {
                     // descend into the last child that was hit; the others wait on the stack
                     // (the host has checked that CAND_STACK entries are enough for this tree)
                     if (next >= 0) lds.stack[sp++ * lds.stride] = (uint16_t)next;
-                    next = child;
+                    next = child[k];
                     continue;
                 }
                 // mark the leaf: an LDS OR that returns nothing
-                const int leaf = -2 - child;
+                const int leaf = -2 - child[k];
                 (void)__hip_atomic_fetch_or(bits + (leaf >> 5) * lds.stride, 1u << (leaf & 31), __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_WORKGROUP);
                 touched |= 1u << (leaf >> 5);
@@ -1053,7 +1115,7 @@ __device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng
         if (i >= resume) {
             if constexpr ((FEAT & FEAT_SPHERE) != 0) {
                 if (flags & NODE_DYNAMIC_BOX)
-                    dynamic_leaf_box(as_const(sv.objects) + obj, t_min, closest, mn, mx);
+                    dynamic_leaf_box(as_const(sv.objects) + obj, r->p, r->identity != 0, t_min, closest, mn, mx);
             }
             pass = aabb_hit(mn, mx, ray, inv_d, t_min, closest);
             if (!pass) resume = skip;

@@ -434,16 +434,24 @@ int collapse(const std::vector<Cand2>& b2, int i, std::vector<DCand4>* out, int*
     DCand4 nd{};
     std::vector<Kid> all(inner);
     all.insert(all.end(), leaves.begin(), leaves.end());
+    // f32 bounds rounded outward: the stored box contains the exact one
+    auto down = [](double x) {
+        float f = (float)x;
+        return (double)f > x ? std::nextafterf(f, -INFINITY) : f;
+    };
+    auto up = [](double x) {
+        float f = (float)x;
+        return (double)f < x ? std::nextafterf(f, INFINITY) : f;
+    };
     for (int k = 0; k < 4; ++k) {
         nd.child[k] = -1;
-        for (int a = 0; a < 3; ++a) nd.lo[a][k] = INFINITY, nd.hi[a][k] = -INFINITY;
+        for (int a = 0; a < 3; ++a) nd.lo[a][k] = INFINITY, nd.hi[a][k] = -INFINITY, nd.vlo[a][k] = 0.f, nd.vhi[a][k] = 0.f;
         if ((size_t)k >= all.size()) continue;
         const Cand2& c = b2[(size_t)all[(size_t)k].b2];
         nd.child[k] = all[(size_t)k].index;
         for (int a = 0; a < 3; ++a) {
-            nd.lo[a][k] = c.lo[a], nd.hi[a][k] = c.hi[a];
-            nd.v_for_lo[0][a][k] = c.vlo[a], nd.v_for_lo[1][a][k] = c.vhi[a];
-            nd.v_for_hi[0][a][k] = c.vhi[a], nd.v_for_hi[1][a][k] = c.vlo[a];
+            nd.lo[a][k] = down(c.lo[a]), nd.hi[a][k] = up(c.hi[a]);
+            nd.vlo[a][k] = down(c.vlo[a]), nd.vhi[a][k] = up(c.vhi[a]);
             if (c.vlo[a] != 0.0 || c.vhi[a] != 0.0) nd.moving = 1;
         }
     }

@@ -96,21 +96,24 @@ struct DNode {
 };
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
 
-// Node of the spatial tree of the candidate search: four children with their boxes, one record
-// per visit. A child's box at ray time tau is [lo + min(tau * vlo, tau * vhi), hi + max(tau * vlo,
-// tau * vhi)]: a MovingSphere's centre is linear in the ray's time (sphere.rs:139-142), and
-// scattered rays carry arbitrary times (ray_tracer.rs:242,261 set time = hit t), so the bound has
-// to hold for every tau. The velocity bounds are stored twice, indexed by the sign of tau, which
-// turns the min/max of the interval product into one fma per corner.
-struct DCand4 {
+// Node of the spatial tree of the candidate search: four children with their boxes. The search is
+// bound by the cache lines its per-lane (divergent) node loads touch, so a node is two 128-byte lines:
+// the first holds the child links and the boxes at ray time 0, the second the velocity bounds, which only
+// nodes with a moving child read. Bounds are f32, rounded OUTWARD from the f64 boxes on the host (lower
+// bounds down, upper bounds up), so the stored boxes contain the exact ones and the search stays a
+// superset filter; the device converts them back to f64 and tests in f64.
+// A child's box at ray time tau is [lo + min(tau * vlo, tau * vhi), hi + max(tau * vlo, tau * vhi)]: a
+// MovingSphere's centre is linear in the ray's time (sphere.rs:139-142), and scattered rays carry arbitrary
+// times (ray_tracer.rs:242,261 set time = hit t), so the bound has to hold for every tau.
+struct alignas(128) DCand4 {
     int32_t child[4];  // >= 0: node index; -1: none; <= -2: leaf, index (-2 - child) in FlatScene::nodes
-    int32_t moving;    // 0: every velocity bound is 0
+    float lo[3][4], hi[3][4];
+    int32_t moving;    // 0: every velocity bound is 0 (the second line is not read)
     int32_t pad[3];
-    double lo[3][4], hi[3][4];
-    double v_for_lo[2][3][4];  // [tau < 0]: velocity bound that gives the lower corner
-    double v_for_hi[2][3][4];  // [tau < 0]: velocity bound that gives the upper corner
+    float vlo[3][4], vhi[3][4];  // velocity bounds per unit of ray time
+    int32_t pad2[8];
 };
-static_assert(sizeof(DCand4) == 608, "DCand4 layout");
+static_assert(sizeof(DCand4) == 256, "DCand4 is two 128-byte lines");
 
 // One self-contained record per device BVH node for the wave-synchronous walk: everything the
 // box test and the leaf's intersection test need, so a node costs one batch of scalar loads
