@@ -39,6 +39,7 @@ namespace mrt {
 // ============================================================== device-side views
 struct SceneView {
     const DNode* nodes;  // the tree for the per-lane walk
+    const DLeafRec* lane_leaf;  // per node: the leaf's shape record (per-lane walk)
     const DNodeRec* node_recs;  // what the wave-synchronous walk visits: the tree, or its leaf list
     int32_t n_wave_nodes;
     int32_t n_nodes;
@@ -845,28 +846,19 @@ struct LaneWalk {
 };
 // One node visit of the walk: the node's box test against the running bound and, for a leaf that
 // passes, the object's intersection test(s). Returns whether the box test passed.
+// The leaf's shape record `lr` comes with the node (same index, requested together with it), so a visit
+// costs one round trip to memory; the object record itself is only touched for objects with a transform.
 template <int FEAT>
-__device__ __forceinline__ bool lane_visit(const SceneView& sv, const DNode& nd, const RayD& ray, D3 inv_d, const Rng& g,
-                                           LaneWalk& w) {
+__device__ __forceinline__ bool lane_visit(const SceneView& sv, const DNode& nd, const DLeafRec& lr, const RayD& ray, D3 inv_d,
+                                           const Rng& g, LaneWalk& w) {
     const double t_min = (double)0.001f;
     const int obj = nd.object;
     const int flags = nd.flags;
     D3 mn{nd.bmin[0], nd.bmin[1], nd.bmin[2]};
     D3 mx{nd.bmax[0], nd.bmax[1], nd.bmax[2]};
-    // A leaf's record head (kinds, identity flag) and shape parameters are requested together, before the
-    // box test decides whether they are needed: the loads are independent of each other, and a lane's walk
-    // is a chain of dependent fetches that every load issued later, inside a branch, would lengthen.
     const DObjRec* ob = sv.objects + (obj >= 0 ? obj : 0);
-    int4 head{0, 0, 0, 0};
-    double p[10];
-    if (obj >= 0) {
-        head = *reinterpret_cast<const int4*>(&ob->kind);  // kind, gkind, identity, octree
-#pragma unroll
-        for (int i = 0; i < 10; i += 2) {
-            const double2 v = *reinterpret_cast<const double2*>(&ob->p[i]);
-            p[i] = v.x, p[i + 1] = v.y;
-        }
-    }
+    const int4 head{lr.kind, lr.gkind, lr.identity, lr.octree};
+    const double* p = lr.p;
     const bool identity = head.z != 0;
     if constexpr ((FEAT & FEAT_SPHERE) != 0) {
         if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(ob, p, identity, t_min, w.closest, mn, mx);
@@ -1030,11 +1022,13 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
     bool last_parent_pass = true;
     int idx = next_marked();
     DNode nd{};
-    if (idx >= 0) nd = sv.nodes[idx];
+    DLeafRec lr{};
+    if (idx >= 0) nd = sv.nodes[idx], lr = sv.lane_leaf[idx];
     while (idx >= 0) {
         const int idx_next = next_marked();
         DNode nd_next{};
-        if (idx_next >= 0) nd_next = sv.nodes[idx_next];
+        DLeafRec lr_next{};
+        if (idx_next >= 0) nd_next = sv.nodes[idx_next], lr_next = sv.lane_leaf[idx_next];
         STAMP_COUNT(st, 2);
         bool reach = true;
         if constexpr ((FEAT & FEAT_SPHERE) != 0) {
@@ -1052,9 +1046,10 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
                 reach = last_parent_pass;
             }
         }
-        if (reach) (void)lane_visit<FEAT>(sv, nd, ray, inv_d, g, w);
+        if (reach) (void)lane_visit<FEAT>(sv, nd, lr, ray, inv_d, g, w);
         idx = idx_next;
         nd = nd_next;
+        lr = lr_next;
     }
     out.t = w.closest;
     out.obj = w.best_obj;
@@ -1077,7 +1072,8 @@ __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng
     const int n = sv.n_nodes;
     while (i < n) {
         const DNode nd = sv.nodes[i];
-        i = lane_visit<FEAT>(sv, nd, ray, inv_d, g, w) ? i + 1 : nd.skip;
+        const DLeafRec lr = sv.lane_leaf[i];
+        i = lane_visit<FEAT>(sv, nd, lr, ray, inv_d, g, w) ? i + 1 : nd.skip;
     }
     out.t = w.closest;
     out.obj = w.best_obj;
@@ -1860,8 +1856,12 @@ constexpr size_t lds_bytes(bool wave, int feat, int threads) {
     if (!wave) return (sizeof(uint32_t) * CAND_WORDS + sizeof(uint16_t) * CAND_STACK) * (size_t)threads;
     return 0;
 }
+#ifndef MRT_LANE_WAVES
+#define MRT_LANE_WAVES 3
+#endif
 constexpr int seg_waves(bool wave, int feat) {
-    return (wave && (feat & (FEAT_SPECULAR | FEAT_TEXTURE)) != 0) ? 2 : 3;
+    if (!wave) return MRT_LANE_WAVES;
+    return (feat & (FEAT_SPECULAR | FEAT_TEXTURE)) != 0 ? 2 : 3;
 }
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
@@ -2317,7 +2317,8 @@ struct mrt_scene {
 template <int... M>
 struct FeatList {};
 constexpr int FEAT_NO_OCTREE = FEAT_ALL & ~(FEAT_OCTREE | FEAT_VOLUME);
-using KernelFeats = FeatList<0, FEAT_MEDIUM, FEAT_SPHERE | FEAT_MEDIUM, FEAT_SPHERE | FEAT_SPECULAR | FEAT_TEXTURE | FEAT_SKY,
+using KernelFeats = FeatList<0, FEAT_MEDIUM, FEAT_SPHERE | FEAT_MEDIUM, FEAT_SPHERE | FEAT_SPECULAR | FEAT_SKY,
+                             FEAT_SPHERE | FEAT_SPECULAR | FEAT_TEXTURE | FEAT_SKY,
                              FEAT_NO_OCTREE, FEAT_OCTREE | FEAT_SKY, FEAT_OCTREE | FEAT_SPHERE | FEAT_SKY,
                              FEAT_OCTREE | FEAT_VOLUME | FEAT_SPHERE | FEAT_SKY, FEAT_ALL>;
 // The single-bounce shaders (debug views) are instantiated for two sets only.
@@ -2385,7 +2386,7 @@ int upload_scene(mrt_scene* sc) {
     int rc;
 #define UP(vec, field)                                       \
     if ((rc = m.upload(vec, &v.field)) != MRT_OK) return rc;
-    UP(f.nodes, nodes)
+    UP(f.nodes, nodes) UP(f.lane_leaf, lane_leaf)
     if ((rc = m.upload(f.node_recs, &sc->dev_node_recs)) != MRT_OK) return rc;
     if ((rc = m.upload(f.leaf_recs, &sc->dev_leaf_recs)) != MRT_OK) return rc;
     UP(f.cand_nodes, cand_nodes)

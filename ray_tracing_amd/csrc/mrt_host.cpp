@@ -798,6 +798,15 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
                 if (s.nodes[i].object < 0) open.push_back((int32_t)i);
             }
         }
+        // per-node leaf records of the per-lane walk (same index as `nodes`)
+        s.lane_leaf.assign(s.nodes.size(), DLeafRec{});
+        for (size_t i = 0; i < s.nodes.size(); ++i) {
+            if (s.nodes[i].object < 0) continue;
+            const DObjRec& r = s.obj_recs[(size_t)s.nodes[i].object];
+            DLeafRec& l = s.lane_leaf[i];
+            l.kind = r.kind, l.gkind = r.gkind, l.identity = r.identity, l.octree = r.octree;
+            std::memcpy(l.p, r.p, sizeof(l.p));
+        }
         // self-contained node records for the wave-synchronous walk
         s.node_recs.resize(s.node_object.size());
         for (size_t i = 0; i < s.node_recs.size(); ++i) {

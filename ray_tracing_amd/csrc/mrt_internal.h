@@ -96,6 +96,14 @@ struct DNode {
 };
 static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
 
+// What the per-lane walk needs of a leaf's object besides the box, stored per NODE (same index as DNode),
+// so that a node visit requests both records at once instead of node -> object one after the other.
+struct DLeafRec {
+    int32_t kind, gkind, identity, octree;  // as in DObjRec (zero for inner nodes)
+    double p[10];                           // geometry parameters (media: the boundary's, and p[9] = -1/density)
+};
+static_assert(sizeof(DLeafRec) == 96, "DLeafRec layout");
+
 // Node of the spatial tree of the candidate search: four children with their boxes. The search is
 // bound by the cache lines its per-lane (divergent) node loads touch, so a node is two 128-byte lines:
 // the first holds the child links and the boxes at ray time 0, the second the velocity bounds, which only
@@ -180,6 +188,7 @@ struct FlatScene {
     std::vector<double> bmin[3], bmax[3];
     std::vector<int32_t> node_object, node_skip, node_flags;
     std::vector<DNode> nodes;
+    std::vector<DLeafRec> lane_leaf;  // per node of `nodes`
     std::vector<DNodeRec> node_recs;
     // The leaves of node_recs in the same (pre-)order, each linked to the next one. A leaf's box lies
     // inside the boxes of its ancestors, so an ancestor's test can only reject rays the leaf's own box
