@@ -128,9 +128,21 @@ def committed_profile(workload_key):
     return best
 
 
+def scene_name(name):
+    """Display name of a scenario given either the display name or its key form (`random_scene`, `voxel_city`)."""
+    from ray_tracing_amd import scenarios
+    names = list(scenarios.SCENARIOS) + ["Light Demonstration", "Easy Scene", "Voxel City", "Fast Oct Tree Apartment Building",
+                                         "Fast Oct Tree Sinnoh"]
+    key = name.lower().replace(",", "").replace(" ", "_")
+    for n in names:
+        if n.lower().replace(",", "").replace(" ", "_") == key:
+            return n
+    raise SystemExit(f"unknown scene {name!r}; known: {sorted(names)}")
+
+
 def build_scene(name):
     from ray_tracing_amd import scenarios
-    if name in ("Cornell Smoke", "cornell_smoke"):
+    if name == "Cornell Smoke":
         return scenarios.cornell_smoke()
     from tests.helpers import scene_by_name   # data fixtures (decoded .vox, earthmap) live under tests/golden
     return scene_by_name(name)
@@ -194,6 +206,7 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    args.scene = scene_name(args.scene)
     W, H = args.width, args.height
     total_spp = args.spp if args.strong else args.spp * world_size
     my_first, my_spp = sample_range(total_spp, rank, world_size)

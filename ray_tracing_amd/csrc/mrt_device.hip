@@ -734,11 +734,14 @@ template <int FEAT, class PP, class AP>
 __device__ __forceinline__ bool leaf_hit(const SceneView& sv, int kind, int bkind, int octree, PP p,
                                          double neg_inv_density, bool identity, AP to_object, const RayD& ray,
                                          D3 inv_world, double t_min, double t_max, const Rng& g, uint32_t medium_dim,
-                                         uint32_t& oct_entry, double& t, int& sub, D3& pos) {
+                                         uint32_t& oct_entry, double& t, int& sub, D3& pos, bool translation = false) {
 #pragma clang fp contract(off)
     RayD sr = ray;
     D3 inv = inv_world;
-    if (!identity) {
+    if (translation) {
+        // a pure translation leaves the direction alone (the reference's M*(o+d) - M*o differs from d only by rounding)
+        sr.o = {ray.o.x + to_object->r[0][3], ray.o.y + to_object->r[1][3], ray.o.z + to_object->r[2][3]};
+    } else if (!identity) {
         sr = xform_ray(to_object, false, ray);
         inv = {rcp_fast(sr.d.x), rcp_fast(sr.d.y), rcp_fast(sr.d.z)};
     }
@@ -803,7 +806,7 @@ __device__ __forceinline__ bool node_hit(const SceneView& sv, RP r, const RayD& 
                                          double t_max, const Rng& g, uint32_t medium_dim, uint32_t& oct_entry, double& t,
                                          int& sub, D3& pos) {
     return leaf_hit<FEAT>(sv, r->kind, r->kind2, r->octree, &r->p[0], r->p[9], r->identity != 0, &r->to_object, ray,
-                          inv_world, t_min, t_max, g, medium_dim, oct_entry, t, sub, pos);
+                          inv_world, t_min, t_max, g, medium_dim, oct_entry, t, sub, pos, r->identity == 0 && r->translation != 0);
 }
 
 // Leaf box of a MovingSphere-based object for the time window (t0, t1) the reference passes

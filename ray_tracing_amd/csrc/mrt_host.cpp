@@ -822,6 +822,10 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
                 const DShape* sh = &s.shapes[(size_t)ob.shape];
                 r.kind = sh->kind;
                 r.identity = ob.identity;
+                r.translation = 1;
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b)
+                        if (ob.to_object.r[a][b] != (a == b ? 1.0 : 0.0)) r.translation = 0;
                 r.octree = sh->octree;
                 r.to_object = ob.to_object;
                 if (sh->kind == MRT_SHAPE_CONSTANT_MEDIUM) {

@@ -135,7 +135,7 @@ struct DNodeRec {
     int32_t identity;  // object transform is the identity
     int32_t kind2;     // media: kind of the boundary shape
     int32_t octree;    // octree index for OCTREE leaves
-    int32_t pad;
+    int32_t translation;  // the object transform is a pure translation (linear part exactly the identity)
     double p[10];      // shape parameters (media: the boundary's, and p[9] = -1/density)
     Affine to_object;  // world -> object (used when !identity)
 };

@@ -76,7 +76,8 @@ def main():
             if mix_line and "sq" in res:
                 rays = mix_line["mrays_per_s"] * 1e6 * mix_line["ms_per_step"] * 1e-3 * (mix_line["steps"] + mix_line["warmup"])
                 res["f64_mix"]["segments_in_run"] = rays
-                res["f64_mix"]["valu_insts_per_wave_segment"] = a["SQ_INSTS_VALU"] * 64.0 * res["sq"]["lane_utilisation"] / rays / 64.0
+                res["f64_mix"]["valu_wave_insts_per_64_segments"] = a["SQ_INSTS_VALU"] * 64.0 / rays
+                res["f64_mix"]["valu_lane_insts_per_segment"] = a["SQ_INSTS_VALU"] * 64.0 * res["sq"]["lane_utilisation"] / rays
                 res["f64_mix"]["f64_flops_per_segment"] = f64_wave_ops * 64.0 * res["sq"]["lane_utilisation"] / rays
                 res["f64_mix"]["source"] = ("rocprofv3 SQ_INSTS_VALU_{ADD,MUL,TRANS,FMA x2}_F64 wave instructions x 64 lanes x "
                                             "lane utilisation / path segments of the profiled run")
