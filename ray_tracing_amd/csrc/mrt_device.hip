@@ -862,7 +862,7 @@ __device__ __forceinline__ bool lane_visit(const SceneView& sv, const DNode& nd,
     const DObjRec* ob = sv.objects + (obj >= 0 ? obj : 0);
     const int4 head{lr.kind, lr.gkind, lr.identity, lr.octree};
     const double* p = lr.p;
-    const bool identity = head.z != 0;
+    const bool identity = head.z == 1, translation = head.z == 2;
     if constexpr ((FEAT & FEAT_SPHERE) != 0) {
         if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(ob, p, identity, t_min, w.closest, mn, mx);
     }
@@ -877,7 +877,7 @@ __device__ __forceinline__ bool lane_visit(const SceneView& sv, const DNode& nd,
             double t;
             int sub;
             if (leaf_hit<FEAT>(sv, head.x, head.y, head.w, p, p[9], identity, &ob->to_object, ray, inv_d, t_min, w.closest, g,
-                               MRT_DIM_MEDIUM + w.medium_ordinal, w.oct_entry, t, sub, w.best_pos)) {
+                               MRT_DIM_MEDIUM + w.medium_ordinal, w.oct_entry, t, sub, w.best_pos, translation)) {
                 w.closest = t, w.best_obj = obj, w.best_sub = sub;
             }
             if (is_medium) w.medium_ordinal++;

@@ -804,7 +804,11 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
             if (s.nodes[i].object < 0) continue;
             const DObjRec& r = s.obj_recs[(size_t)s.nodes[i].object];
             DLeafRec& l = s.lane_leaf[i];
-            l.kind = r.kind, l.gkind = r.gkind, l.identity = r.identity, l.octree = r.octree;
+            bool translation = true;  // linear part exactly the identity
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) translation = translation && r.to_object.r[a][b] == (a == b ? 1.0 : 0.0);
+            l.kind = r.kind, l.gkind = r.gkind, l.octree = r.octree;
+            l.identity = r.identity ? 1 : (translation ? 2 : 0);
             std::memcpy(l.p, r.p, sizeof(l.p));
         }
         // self-contained node records for the wave-synchronous walk

@@ -99,7 +99,7 @@ static_assert(sizeof(DNode) == 64, "DNode must be one 64-byte line");
 // What the per-lane walk needs of a leaf's object besides the box, stored per NODE (same index as DNode),
 // so that a node visit requests both records at once instead of node -> object one after the other.
 struct DLeafRec {
-    int32_t kind, gkind, identity, octree;  // as in DObjRec (zero for inner nodes)
+    int32_t kind, gkind, identity, octree;  // as in DObjRec (zero for inner nodes); identity: 1 identity, 2 pure translation
     double p[10];                           // geometry parameters (media: the boundary's, and p[9] = -1/density)
 };
 static_assert(sizeof(DLeafRec) == 96, "DLeafRec layout");

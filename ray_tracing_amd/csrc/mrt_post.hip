@@ -10,6 +10,8 @@
 
 #include <cmath>
 #include <cstdint>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -145,6 +147,19 @@ struct Scratch {
     }
 };
 
+// Work images of mrt_bloom_device, kept per device between calls (an interactive caller blooms every
+// frame at one size; allocating and freeing ten buffers per call cost more than the kernels). Replaced
+// when the image size changes; calls on one device take turns.
+struct BloomWork {
+    std::mutex mu;
+    uint32_t width = 0, height = 0;
+    std::unique_ptr<Scratch> mem;
+    float *original = nullptr, *tmp_a = nullptr, *tmp_b = nullptr;
+    float* level[LEVELS + 1] = {};
+};
+constexpr int MAX_DEVICES = 64;
+BloomWork g_bloom_work[MAX_DEVICES];
+
 inline dim3 grid_for(size_t n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); }
 
 }  // namespace mrt_post
@@ -165,21 +180,31 @@ int mrt_bloom_device(int device, const float* accum_rgb_device, uint32_t width, 
     // the reference panics when the last pyramid level is narrower than two pixels (parallel_image.rs:216-217)
     if ((width >> LEVELS) < 2 || (height >> LEVELS) < 2)
         return fail(MRT_ERR_UNSUPPORTED, "bloom needs an image of at least 128x128 (the reference panics below that)");
+    if (device < 0 || device >= MAX_DEVICES) return fail(MRT_ERR_INVALID_ARGUMENT, "device ordinal out of range");
     if (hipSetDevice(device) != hipSuccess) return fail(MRT_ERR_DEVICE, "hipSetDevice failed");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    Scratch mem;
+    BloomWork& work = g_bloom_work[device];
+    std::lock_guard<std::mutex> turn(work.mu);
     int w[LEVELS + 1], h[LEVELS + 1];
-    float* level[LEVELS + 1];
     w[0] = (int)width, h[0] = (int)height;
     for (int i = 1; i <= LEVELS; ++i) w[i] = w[i - 1] / 2, h[i] = h[i - 1] / 2;
     const size_t n0 = (size_t)width * height;
-    float* original = mem.get(3 * n0);
-    float* tmp_a = mem.get(3 * n0);  // bright image / down-sampled input
-    float* tmp_b = mem.get(3 * n0);  // x-blurred
-    for (int i = 0; i <= LEVELS; ++i) level[i] = mem.get(3 * (size_t)w[i] * h[i]);
-    if (!original || !tmp_a || !tmp_b) return fail(MRT_ERR_OUT_OF_MEMORY, "hipMalloc failed");
-    for (int i = 0; i <= LEVELS; ++i)
-        if (!level[i]) return fail(MRT_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+    if (!work.mem || work.width != width || work.height != height) {
+        work.mem.reset(new Scratch());
+        work.width = work.height = 0;
+        work.original = work.mem->get(3 * n0);
+        work.tmp_a = work.mem->get(3 * n0);  // bright image / down-sampled input
+        work.tmp_b = work.mem->get(3 * n0);  // x-blurred
+        bool ok = work.original && work.tmp_a && work.tmp_b;
+        for (int i = 0; i <= LEVELS; ++i) ok = (work.level[i] = work.mem->get(3 * (size_t)w[i] * h[i])) != nullptr && ok;
+        if (!ok) {
+            work.mem.reset();
+            return fail(MRT_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+        }
+        work.width = width, work.height = height;
+    }
+    float *original = work.original, *tmp_a = work.tmp_a, *tmp_b = work.tmp_b;
+    float** level = work.level;
 
     hipLaunchKernelGGL(k_select, grid_for(n0), dim3(BLOCK), 0, stream, accum_rgb_device, (float)num_samples, original, tmp_a,
                        (uint32_t)n0);
