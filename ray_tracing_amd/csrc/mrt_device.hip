@@ -63,12 +63,30 @@ struct SceneView {
     mrt_sun sun;
 };
 
+// The path pool: ONE block of memory holding, for `cap` slots, seven f64 arrays (ray origin, direction,
+// time), the RNG keys, three f32 arrays (throughput), the pixel indices and the segment counters. A kernel
+// gets the block's address and `cap` (three SGPRs instead of thirteen array pointers that would stay live
+// across the whole segment loop) and forms an array's address where it is used.
 struct Pool {
-    double *ox, *oy, *oz, *dx, *dy, *dz, *tm;
-    float *tr, *tg, *tb;
-    uint32_t* pixel;
-    uint64_t* key;
-    int32_t* seg;  // >= 0: index of the next segment of a live path; < 0: free slot
+    unsigned char* base;
+    unsigned long long cap;  // slots per array, a multiple of 64
+    __host__ __device__ double* f64(int k) const { return reinterpret_cast<double*>(base) + (size_t)k * cap; }
+    __host__ __device__ double* ox() const { return f64(0); }
+    __host__ __device__ double* oy() const { return f64(1); }
+    __host__ __device__ double* oz() const { return f64(2); }
+    __host__ __device__ double* dx() const { return f64(3); }
+    __host__ __device__ double* dy() const { return f64(4); }
+    __host__ __device__ double* dz() const { return f64(5); }
+    __host__ __device__ double* tm() const { return f64(6); }
+    __host__ __device__ uint64_t* key() const { return reinterpret_cast<uint64_t*>(base) + (size_t)7 * cap; }
+    __host__ __device__ float* f32(int k) const { return reinterpret_cast<float*>(base + (size_t)64 * cap) + (size_t)k * cap; }
+    __host__ __device__ float* tr() const { return f32(0); }
+    __host__ __device__ float* tg() const { return f32(1); }
+    __host__ __device__ float* tb() const { return f32(2); }
+    __host__ __device__ uint32_t* pixel() const { return reinterpret_cast<uint32_t*>(base + (size_t)76 * cap); }
+    // >= 0: index of the next segment of a live path; < 0: free slot
+    __host__ __device__ int32_t* seg() const { return reinterpret_cast<int32_t*>(base + (size_t)80 * cap); }
+    static constexpr size_t bytes(size_t cap) { return (size_t)84 * cap; }
 };
 // Work items (pixel-samples) are handed out in chunks: a wave takes WORK_CHUNK consecutive items
 // from the global counter with one atomic and serves its lanes from that range; what is left of
@@ -1885,14 +1903,14 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
     uint32_t pixel = 0;
     uint64_t key = 0;
     if (in_range) {
-        seg = pool.seg[slot];
+        seg = pool.seg()[slot];
         if (seg >= 0) {
-            ray.o = {pool.ox[slot], pool.oy[slot], pool.oz[slot]};
-            ray.d = {pool.dx[slot], pool.dy[slot], pool.dz[slot]};
-            ray.time = pool.tm[slot];
-            thr = {pool.tr[slot], pool.tg[slot], pool.tb[slot]};
-            pixel = pool.pixel[slot];
-            key = pool.key[slot];
+            ray.o = {pool.ox()[slot], pool.oy()[slot], pool.oz()[slot]};
+            ray.d = {pool.dx()[slot], pool.dy()[slot], pool.dz()[slot]};
+            ray.time = pool.tm()[slot];
+            thr = {pool.tr()[slot], pool.tg()[slot], pool.tb()[slot]};
+            pixel = pool.pixel()[slot];
+            key = pool.key()[slot];
         }
     }
     uint32_t rays = 0, light_queries = 0;
@@ -1994,14 +2012,14 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
         if (st.count[i]) atomicAdd(&ctr->stamp_counts[i], (unsigned long long)st.count[i]);
 #endif
     if (in_range) {
-        pool.seg[slot] = seg;
+        pool.seg()[slot] = seg;
         if (seg >= 0) {
-            pool.ox[slot] = ray.o.x, pool.oy[slot] = ray.o.y, pool.oz[slot] = ray.o.z;
-            pool.dx[slot] = ray.d.x, pool.dy[slot] = ray.d.y, pool.dz[slot] = ray.d.z;
-            pool.tm[slot] = ray.time;
-            pool.tr[slot] = thr.r, pool.tg[slot] = thr.g, pool.tb[slot] = thr.b;
-            pool.pixel[slot] = pixel;
-            pool.key[slot] = key;
+            pool.ox()[slot] = ray.o.x, pool.oy()[slot] = ray.o.y, pool.oz()[slot] = ray.o.z;
+            pool.dx()[slot] = ray.d.x, pool.dy()[slot] = ray.d.y, pool.dz()[slot] = ray.d.z;
+            pool.tm()[slot] = ray.time;
+            pool.tr()[slot] = thr.r, pool.tg()[slot] = thr.g, pool.tb()[slot] = thr.b;
+            pool.pixel()[slot] = pixel;
+            pool.key()[slot] = key;
         }
     }
     uint32_t live = wave_sum(seg >= 0 ? 1u : 0u);
@@ -2124,7 +2142,7 @@ __global__ void __launch_bounds__(BLOCK) k_single_bounce(SceneView sv, RenderPar
 
 __global__ void __launch_bounds__(BLOCK) k_init_pool(Pool pool, uint32_t n, unsigned long long* wave_chunks) {
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) pool.seg[i] = -1;
+    if (i < n) pool.seg()[i] = -1;
     if (i < n && (i & 63) == 0) wave_chunks[2 * (size_t)(i >> 6)] = 0, wave_chunks[2 * (size_t)(i >> 6) + 1] = 0;
 }
 
@@ -2132,7 +2150,7 @@ __global__ void __launch_bounds__(BLOCK) k_init_pool(Pool pool, uint32_t n, unsi
 // (wave64 ballot + popcount prefix, one atomic per wave).
 __global__ void __launch_bounds__(BLOCK) k_compact(Pool src, Pool dst, uint32_t n, Counters* ctr) {
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    bool alive = i < n && src.seg[i] >= 0;
+    bool alive = i < n && src.seg()[i] >= 0;
     unsigned long long mask = __ballot(alive);
     if (!mask) return;
     uint32_t base = 0;
@@ -2141,13 +2159,13 @@ __global__ void __launch_bounds__(BLOCK) k_compact(Pool src, Pool dst, uint32_t 
     base = __shfl(base, leader, 64);
     if (alive) {
         uint32_t j = base + (uint32_t)__popcll(mask & ((1ULL << lane_id()) - 1ULL));
-        dst.ox[j] = src.ox[i], dst.oy[j] = src.oy[i], dst.oz[j] = src.oz[i];
-        dst.dx[j] = src.dx[i], dst.dy[j] = src.dy[i], dst.dz[j] = src.dz[i];
-        dst.tm[j] = src.tm[i];
-        dst.tr[j] = src.tr[i], dst.tg[j] = src.tg[i], dst.tb[j] = src.tb[i];
-        dst.pixel[j] = src.pixel[i];
-        dst.key[j] = src.key[i];
-        dst.seg[j] = src.seg[i];
+        dst.ox()[j] = src.ox()[i], dst.oy()[j] = src.oy()[i], dst.oz()[j] = src.oz()[i];
+        dst.dx()[j] = src.dx()[i], dst.dy()[j] = src.dy()[i], dst.dz()[j] = src.dz()[i];
+        dst.tm()[j] = src.tm()[i];
+        dst.tr()[j] = src.tr()[i], dst.tg()[j] = src.tg()[i], dst.tb()[j] = src.tb()[i];
+        dst.pixel()[j] = src.pixel()[i];
+        dst.key()[j] = src.key()[i];
+        dst.seg()[j] = src.seg()[i];
     }
 }
 
@@ -2211,16 +2229,12 @@ using namespace mrt;
 constexpr uint32_t NOALLOC_SLOTS = 3072u * 64u;
 constexpr size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
 struct ScratchLayout {
-    size_t f64[7], f32[3], pixel, key, seg, counters, wave_chunks, total;
+    size_t pool, counters, wave_chunks, total;
 };
 constexpr ScratchLayout scratch_layout() {
     ScratchLayout l{};
     size_t off = 0;
-    for (int i = 0; i < 7; ++i) l.f64[i] = off, off += align256(sizeof(double) * NOALLOC_SLOTS);
-    for (int i = 0; i < 3; ++i) l.f32[i] = off, off += align256(sizeof(float) * NOALLOC_SLOTS);
-    l.pixel = off, off += align256(sizeof(uint32_t) * NOALLOC_SLOTS);
-    l.key = off, off += align256(sizeof(uint64_t) * NOALLOC_SLOTS);
-    l.seg = off, off += align256(sizeof(int32_t) * NOALLOC_SLOTS);
+    l.pool = off, off += align256(Pool::bytes(NOALLOC_SLOTS));
     l.counters = off, off += align256(sizeof(Counters));
     l.wave_chunks = off, off += align256(sizeof(unsigned long long) * 2 * (NOALLOC_SLOTS / 64));
     l.total = off;
@@ -2418,15 +2432,8 @@ int ensure_pool(mrt_scene* sc) {
     int rc;
     for (int b = 0; b < 2; ++b) {
         Pool& p = sc->pool[b];
-        double** d7[7] = {&p.ox, &p.oy, &p.oz, &p.dx, &p.dy, &p.dz, &p.tm};
-        for (auto dp : d7)
-            if ((rc = m.alloc(sizeof(double) * want, reinterpret_cast<void**>(dp))) != MRT_OK) return rc;
-        float** f3[3] = {&p.tr, &p.tg, &p.tb};
-        for (auto fp : f3)
-            if ((rc = m.alloc(sizeof(float) * want, reinterpret_cast<void**>(fp))) != MRT_OK) return rc;
-        if ((rc = m.alloc(sizeof(uint32_t) * want, reinterpret_cast<void**>(&p.pixel))) != MRT_OK) return rc;
-        if ((rc = m.alloc(sizeof(uint64_t) * want, reinterpret_cast<void**>(&p.key))) != MRT_OK) return rc;
-        if ((rc = m.alloc(sizeof(int32_t) * want, reinterpret_cast<void**>(&p.seg))) != MRT_OK) return rc;
+        p.cap = want;
+        if ((rc = m.alloc(Pool::bytes(want), reinterpret_cast<void**>(&p.base))) != MRT_OK) return rc;
     }
     if ((rc = m.alloc(sizeof(Counters), reinterpret_cast<void**>(&sc->counters))) != MRT_OK) return rc;
     if ((rc = m.alloc(sizeof(unsigned long long) * 2 * (want / 64), reinterpret_cast<void**>(&sc->wave_chunks))) != MRT_OK) return rc;
@@ -2501,14 +2508,8 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     unsigned long long* wave_chunks = nullptr;
     uint32_t pool_slots = 0;
     if (scratch_ptr) {
-        Pool& p = pools[0];
-        double** d7[7] = {&p.ox, &p.oy, &p.oz, &p.dx, &p.dy, &p.dz, &p.tm};
-        for (int i = 0; i < 7; ++i) *d7[i] = reinterpret_cast<double*>(scratch_ptr + SCRATCH.f64[i]);
-        float** f3[3] = {&p.tr, &p.tg, &p.tb};
-        for (int i = 0; i < 3; ++i) *f3[i] = reinterpret_cast<float*>(scratch_ptr + SCRATCH.f32[i]);
-        p.pixel = reinterpret_cast<uint32_t*>(scratch_ptr + SCRATCH.pixel);
-        p.key = reinterpret_cast<uint64_t*>(scratch_ptr + SCRATCH.key);
-        p.seg = reinterpret_cast<int32_t*>(scratch_ptr + SCRATCH.seg);
+        pools[0].base = scratch_ptr + SCRATCH.pool;
+        pools[0].cap = NOALLOC_SLOTS;
         counters = reinterpret_cast<Counters*>(scratch_ptr + SCRATCH.counters);
         wave_chunks = reinterpret_cast<unsigned long long*>(scratch_ptr + SCRATCH.wave_chunks);
         pool_slots = NOALLOC_SLOTS;
@@ -2656,7 +2657,7 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
             active = (host.live + BLOCK - 1) / BLOCK * BLOCK;
             if (active > host.live) {
                 // slots between live and the block boundary must read as free
-                HIP_TRY(hipMemsetAsync(pools[cur].seg + host.live, 0xFF, sizeof(int32_t) * (active - host.live), stream));
+                HIP_TRY(hipMemsetAsync(pools[cur].seg() + host.live, 0xFF, sizeof(int32_t) * (active - host.live), stream));
             }
         }
         if (launches > 100000000ull) return set_error(MRT_ERR_DEVICE, "render loop did not terminate");
