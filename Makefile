@@ -7,7 +7,9 @@ LIB := ray_tracing_amd/libmrt.so
 ORACLE := oracle/libmrt_oracle.so
 CSRC := ray_tracing_amd/csrc
 
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function
+# -disable-machine-licm: the segment kernels are one long loop; hoisting constants and kernel arguments out of it
+# (MachineLICM) keeps them in registers across the whole loop, which the allocator then spills to scratch and VGPR lanes
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -munsafe-fp-atomics -mllvm -disable-machine-licm -Wall -Wno-unused-function
 CXXFLAGS := -O3 -std=c++17 -fPIC -Wall -Wextra
 
 all: lib oracle

@@ -1860,10 +1860,7 @@ __device__ __forceinline__ CandLds candidate_lds(const SceneView& sv) {
     for (int w = 0; w < sv.n_cand_words; ++w) lds.bits[w * tpb] = 0;
     return lds;
 }
-// Waves per SIMD the segment kernel is compiled for (512 / waves registers per lane). Measured:
-// three waves hide the scene-record and pool latencies best as long as the kernel fits 168
-// registers without heavy spilling; the wave-synchronous kernels of the large feature sets
-// (specular materials, image / procedural textures) run faster with two.
+// Waves per SIMD the segment kernel is compiled for (512 / waves registers per lane), see seg_waves.
 // Threads per workgroup of the segment kernel: single waves for the wave-synchronous kernels (nothing
 // is shared between the waves of a workgroup, and a wave's slot is free again the moment it ends:
 // +4 % on Cornell smoke, +8 % on the voxel city over 256), 256 for the per-lane kernels (measured
@@ -1882,7 +1879,11 @@ constexpr size_t lds_bytes(bool wave, int feat, int threads) {
 #endif
 constexpr int seg_waves(bool wave, int feat) {
     if (!wave) return MRT_LANE_WAVES;
-    return (feat & (FEAT_SPECULAR | FEAT_TEXTURE)) != 0 ? 2 : 3;
+    // measured per feature set (with the loop's constants and arguments no longer hoisted into registers): the
+    // lean kernels without octree code gain from a fourth wave (Cornell smoke +6 %, Easy Cornell Box +5 %), the
+    // octree walk loses a third of its speed to the spills of 128 registers, the kernels with specular materials
+    // and textures fit three waves now (Easy Scene +19 %)
+    return (feat & (FEAT_SPECULAR | FEAT_TEXTURE | FEAT_OCTREE)) != 0 ? 3 : 4;
 }
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
@@ -2769,6 +2770,8 @@ bool all_reduce_images(const std::vector<int>& devices, const std::vector<float*
 // images are summed on the devices; the strip is downloaded once.
 int render_multi(mrt_scene* const* scenes, uint32_t n_scenes, float* accum_rgb, uint32_t width, uint32_t height,
                  uint32_t x0, uint32_t strip_w, uint32_t spp, uint64_t seed, uint64_t first_sample_index, mrt_stats* stats) {
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (spp == 0) return MRT_OK;
     std::lock_guard<std::mutex> turn(g_multi_mu);
     const auto t_begin = std::chrono::steady_clock::now();
     const size_t n_float = 3 * (size_t)width * height;
