@@ -94,7 +94,7 @@ struct Pool {
 constexpr uint32_t WORK_CHUNK = 1024;
 constexpr int BLOCK = 256;  // threads per workgroup of every kernel here
 
-enum : int { ST_REGEN = 0, ST_TRAVERSE, ST_LEAF, ST_SURFACE, ST_LAMBERT_GEN, ST_LIGHT_VALUE, ST_SHADE, ST_ACCUM, ST_TOTAL, ST_MEDIUM_TAIL, ST_CLAIM, ST_GEN_COS, ST_GEN_LIGHT, ST_GEN_SKY, ST_ISOTROPIC, ST_CAND_SEARCH, ST_COUNT };
+enum : int { ST_REGEN = 0, ST_TRAVERSE, ST_LEAF, ST_SURFACE, ST_LAMBERT_GEN, ST_LIGHT_VALUE, ST_SHADE, ST_ACCUM, ST_TOTAL, ST_MEDIUM_TAIL, ST_CLAIM, ST_GEN_COS, ST_GEN_LIGHT, ST_GEN_SKY, ST_UNIT_VEC, ST_CAND_SEARCH, ST_COUNT };
 struct Counters {
     unsigned long long work_next;
     unsigned long long rays;
@@ -278,6 +278,58 @@ __device__ D3 rand_unit_vec(const Rng& g, uint32_t base, double u0 = -1.0, doubl
         if (dot(v, v) < 1.0) return v;
     }
     return {0.0, 0.0, 0.0};
+}
+// rand_unit_vec for the lanes of a wave that ask for one (`want`, from the Rng base and the dimension base
+// they pass), worked out by the whole wave. Alone, a lane makes 1.9 attempts on average and the wave waits
+// for its unluckiest lane (about five rounds of three draws with a dozen lanes asking) while the other
+// lanes idle. Here the 64 lanes split into groups of 1, 2, 4 or 8 per request; lane a of a group tries
+// attempt first + a of that request (the draws are addressed by dimension, so any lane can make them), the
+// request takes the first attempt of its group that lands in the ball, and requests whose group failed go
+// round again with the next attempts. Same vector as rand_unit_vec, bit for bit. Every lane of the wave
+// must call this together.
+__device__ D3 wave_rand_unit_vec(bool want, uint64_t rng_base, uint32_t dim_base) {
+    D3 out{0.0, 0.0, 0.0};
+    const uint32_t lane = __lane_id();
+    uint32_t first = 0;  // attempts of this lane's request that have failed
+    unsigned long long mask = __ballot(want);
+    while (mask != 0) {
+        const uint32_t n = (uint32_t)__popcll(mask);
+        const uint32_t log_a = n > 32 ? 0u : (n > 16 ? 1u : (n > 8 ? 2u : 3u));  // attempts per request this round
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        // lane q < n learns which lane holds the request of rank q (a permutation of the lanes: the
+        // lanes without a request fill the places from n on)
+        const uint32_t place = want ? rank : n + lane - rank;
+        const int holder = __builtin_amdgcn_ds_permute((int)(place << 2), (int)lane);
+        const uint32_t q = lane >> log_a, a = lane & ((1u << log_a) - 1u);
+        const int from = __builtin_amdgcn_ds_bpermute((int)(q << 2), holder) << 2;  // (some lane without a request for q >= n)
+        const uint32_t b_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)(uint32_t)rng_base);
+        const uint32_t b_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)(uint32_t)(rng_base >> 32));
+        const uint32_t r_dim = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)dim_base);
+        const uint32_t r_first = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)first);
+        const uint32_t attempt = r_first + a;
+        const uint64_t at = (((uint64_t)b_hi << 32) | b_lo) + 0x9E3779B97F4A7C15ULL * (uint64_t)(r_dim + 3u * attempt + 1u);
+        D3 rv{(double)(mix64(at) >> 11) * 0x1.0p-53, (double)(mix64(at + 0x9E3779B97F4A7C15ULL) >> 11) * 0x1.0p-53,
+              (double)(mix64(at + 2u * 0x9E3779B97F4A7C15ULL) >> 11) * 0x1.0p-53};
+        D3 v = 2.0 * (rv - D3{0.5, 0.5, 0.5});
+        const bool ok = q < n && attempt < MRT_MAX_REJECT && dot(v, v) < 1.0;
+        const unsigned long long accepted = __ballot(ok);
+        const uint32_t mine = (uint32_t)(accepted >> (rank << log_a)) & ((1u << (1u << log_a)) - 1u);
+        const bool found = want && mine != 0;
+        const int sel = (int)((found ? (rank << log_a) + (uint32_t)__builtin_ctz(mine) : lane) << 2);
+        D3 got;
+        got.x = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(v.x)), __builtin_amdgcn_ds_bpermute(sel, __double2loint(v.x)));
+        got.y = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(v.y)), __builtin_amdgcn_ds_bpermute(sel, __double2loint(v.y)));
+        got.z = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(v.z)), __builtin_amdgcn_ds_bpermute(sel, __double2loint(v.z)));
+        if (found) {
+            out = got;
+            want = false;
+        } else if (want) {
+            first += 1u << log_a;
+            if (first >= MRT_MAX_REJECT) want = false;  // gives up with the zero vector, as rand_unit_vec does
+        }
+        mask = __ballot(want);
+    }
+    return out;
 }
 
 // Scene records are read through two kinds of pointers: ordinary global pointers when the
@@ -1436,12 +1488,14 @@ __device__ __forceinline__ void rect_generate(double a0, double a1, double b0, d
     o.end_point = end_point;
 }
 template <int FEAT, class OP>
-__device__ void shape_generate(OP sh, D3 origin, double time, const Rng& g, double ua, double ub, AreaInfo& o) {
+__device__ void shape_generate(OP sh, D3 origin, double time, const Rng& g, double ua, double ub, AreaInfo& o,
+                               const D3* unit_vec = nullptr) {
     auto p = sh->p;
     switch (sh->gkind) {  // a medium answers for its boundary (constant_medium.rs:101-103)
         case MRT_SHAPE_SPHERE: {  // sphere.rs:72-87
             if constexpr ((FEAT & FEAT_SPHERE) != 0) {
-                D3 sd = rand_unit_vec(g, MRT_DIM_LIGHT_SPHERE);
+                // (`unit_vec`: the same vector, when the caller had the wave work it out)
+                D3 sd = unit_vec ? *unit_vec : rand_unit_vec(g, MRT_DIM_LIGHT_SPHERE);
                 D3 end_point = D3{p[1], p[2], p[3]} + p[0] * sd;
                 o.to_area = {origin, normalize(end_point - origin), time};
                 o.normal = sd;
@@ -1474,9 +1528,10 @@ __device__ void shape_generate(OP sh, D3 origin, double time, const Rng& g, doub
 }
 // Object::generate_ray_in_area, hittable.rs:289-312
 template <int FEAT, class OP>
-__device__ void object_generate(OP ob, D3 origin, double time, const Rng& g, double ua, double ub, AreaInfo& out) {
+__device__ void object_generate(OP ob, D3 origin, double time, const Rng& g, double ua, double ub, AreaInfo& out,
+                                const D3* unit_vec = nullptr) {
     if (ob->identity) {
-        shape_generate<FEAT>(ob, origin, time, g, ua, ub, out);
+        shape_generate<FEAT>(ob, origin, time, g, ua, ub, out, unit_vec);
         // the reference still routes every vector through the (identity) inverse
         D3 o = out.to_area.o;
         out.to_area.d = (o + out.to_area.d) - o;
@@ -1485,7 +1540,7 @@ __device__ void object_generate(OP ob, D3 origin, double time, const Rng& g, dou
         return;
     }
     AreaInfo a;
-    shape_generate<FEAT>(ob, apply(&ob->to_object, origin), time, g, ua, ub, a);
+    shape_generate<FEAT>(ob, apply(&ob->to_object, origin), time, g, ua, ub, a, unit_vec);
     auto inv = &ob->to_world;
     out.end_point = apply(inv, a.end_point);
     out.to_area = xform_ray(inv, false, a.to_area);
@@ -1557,24 +1612,51 @@ __device__ __forceinline__ D3 sun_direction(const mrt_sun& s) {  // sun.rs:17-20
     return {r * cos(s.theta), sin(s.phi), r * sin(s.theta)};
 }
 
-// LambertianPDF::generate, pdf.rs:234-282. Returns false for None.
+// LambertianPDF::generate, pdf.rs:234-282, in two steps around the wave's unit-vector sampler: the choice of
+// the pdf with the draws every choice starts with (and whether it will need a vector in the unit ball), then
+// the sample itself.
+struct LambertChoice {
+    uint32_t r;      // 0 cosine lobe, 1 light list, 2 sky
+    uint32_t light;  // index into the light list (r == 1)
+    double ua, ub;
+};
 template <int FEAT>
-__device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double incoming_time, D3 hit_point,
-                                    const Rng& g, uint32_t& light_queries, D3& out_dir, double& out_value, Stamps& st) {
-    REGION_BEGIN(gen);
-    Onb uvw = onb_from_w(pdf_normal);
-    uint32_t r = rand_u32(g, 0, 3, MRT_DIM_PDF_CHOICE);
-    // Every branch below starts with two uniforms (cosine lobe: r1, r2; light: the two coordinates on a
-    // flat light; sky: the first two coordinates of the first candidate, or the sun sample). They are
-    // drawn here for all lanes at once, each lane at the dimensions of its own branch, instead of
-    // three times for a third of the lanes.
+__device__ __forceinline__ void lambertian_choose(const SceneView& sv, const Rng& g, LambertChoice& c, bool& want_vec,
+                                                  uint32_t& vec_dim) {
+    const uint32_t r = rand_u32(g, 0, 3, MRT_DIM_PDF_CHOICE);
+    // Every branch starts with two uniforms (cosine lobe: r1, r2; light: the two coordinates on a
+    // flat light; sky: the sun sample). They are drawn here for all lanes at once, each lane at the
+    // dimensions of its own branch, instead of three times for a third of the lanes.
     bool has_sun = false;
     if constexpr ((FEAT & FEAT_SKY) != 0) has_sun = sv.sun.has_sun != 0;
     const uint64_t add_a = r == 0 ? rng_dim_addend(MRT_DIM_COS_R1)
-                                  : (r == 1 ? rng_dim_addend(MRT_DIM_LIGHT_A) : (has_sun ? rng_dim_addend(MRT_DIM_SUN_R) : rng_dim_addend(MRT_DIM_SKY)));
+                                  : (r == 1 ? rng_dim_addend(MRT_DIM_LIGHT_A) : rng_dim_addend(MRT_DIM_SUN_R));
     const uint64_t add_b = r == 0 ? rng_dim_addend(MRT_DIM_COS_R2)
-                                  : (r == 1 ? rng_dim_addend(MRT_DIM_LIGHT_B) : (has_sun ? rng_dim_addend(MRT_DIM_SUN_THETA) : rng_dim_addend(MRT_DIM_SKY + 1)));
-    const double ua = rng_f64_addend(g, add_a), ub = rng_f64_addend(g, add_b);
+                                  : (r == 1 ? rng_dim_addend(MRT_DIM_LIGHT_B) : rng_dim_addend(MRT_DIM_SUN_THETA));
+    c.r = r;
+    c.ua = rng_f64_addend(g, add_a), c.ub = rng_f64_addend(g, add_b);
+    c.light = 0;
+    if (r == 1) {
+        // a one-entry list needs no draw (x % 1 == 0; draws are addressed by dimension)
+        if (sv.n_lights > 1) c.light = rand_u32(g, 0, (uint32_t)sv.n_lights, MRT_DIM_LIGHT_INDEX);
+        if constexpr ((FEAT & FEAT_SPHERE) != 0) {
+            if (sv.n_lights > 0 && sv.lights[c.light].gkind == MRT_SHAPE_SPHERE) want_vec = true, vec_dim = MRT_DIM_LIGHT_SPHERE;
+        }
+    } else if (r == 2 && !has_sun) {
+        want_vec = true, vec_dim = MRT_DIM_SKY;
+    }
+}
+// Returns false for None. `unit_vec`: what rand_unit_vec gives at the dimensions lambertian_choose asked for.
+template <int FEAT>
+__device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double incoming_time, D3 hit_point,
+                                    const Rng& g, const LambertChoice& c, D3 unit_vec, uint32_t& light_queries, D3& out_dir,
+                                    double& out_value, Stamps& st) {
+    REGION_BEGIN(gen);
+    Onb uvw = onb_from_w(pdf_normal);
+    const uint32_t r = c.r;
+    const double ua = c.ua, ub = c.ub;
+    bool has_sun = false;
+    if constexpr ((FEAT & FEAT_SKY) != 0) has_sun = sv.sun.has_sun != 0;
     D3 dir;
     double own;
     if (r == 0) {  // CosinePdf::generate, pdf.rs:45-60; random_cosine_direction, prelude.rs:145-153
@@ -1590,10 +1672,8 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
         REGION_END(st, ST_GEN_COS, gen);
     } else if (r == 1) {  // LightPdf::generate, pdf.rs:104-130
         if (sv.n_lights == 0) return false;
-        // a one-entry list needs no draw (x % 1 == 0; draws are addressed by dimension)
-        uint32_t idx = sv.n_lights == 1 ? 0u : rand_u32(g, 0, (uint32_t)sv.n_lights, MRT_DIM_LIGHT_INDEX);
         AreaInfo ai;
-        object_generate<(FEAT & ~(FEAT_OCTREE | FEAT_VOLUME))>(sv.lights + idx, hit_point, incoming_time, g, ua, ub, ai);
+        object_generate<(FEAT & ~(FEAT_OCTREE | FEAT_VOLUME))>(sv.lights + c.light, hit_point, incoming_time, g, ua, ub, ai, &unit_vec);
         D3 nd = normalize(ai.to_area.d);
         double light_cos = fabs(dot(nd, ai.normal));
         double dist_squared = dot(ai.direction, ai.direction);
@@ -1603,7 +1683,7 @@ __device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double i
         REGION_END(st, ST_GEN_LIGHT, gen);
     } else {  // SkyPdf::generate, pdf.rs:154-193
         if (!has_sun) {
-            dir = rand_unit_vec(g, MRT_DIM_SKY, ua, ub);
+            dir = unit_vec;
             own = 4.0 * M_PI;
         } else if constexpr ((FEAT & FEAT_SKY) != 0) {
             double rr = sqrt(ua);                              // rand_scalar(0, 1)
@@ -1727,10 +1807,21 @@ __device__ __forceinline__ int voxel_material(const SceneView& sv, const Surface
     return MRT_MAT_LAMBERTIAN;
 }
 
-// Material response at the nearest hit `h` (or the background when `hit` is false).
+// Material response at the nearest hit `h` (or the background when `hit` is false), in two steps around
+// the wave's unit-vector sampler (wave_rand_unit_vec): shade_prepare ends the paths that end here (background,
+// light, absorbing metal) and says whether the response needs a vector in the unit ball and at which
+// dimensions; shade_finish, for the lanes shade_prepare returned true for, scatters.
+struct ShadeCtx {
+    const DObjRec* ob;
+    Surface s;
+    int mkind;
+    double fuzz;
+    F3 att;
+    LambertChoice lc;
+};
 template <int FEAT>
-__device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, const HitD& h, bool hit,
-                            F3& radiance, uint32_t& light_queries, Stamps& st) {
+__device__ bool shade_prepare(const SceneView& sv, const RayD& ray, const F3& thr, const Rng& g, const HitD& h, bool hit,
+                              F3& radiance, ShadeCtx& c, bool& want_vec, uint32_t& vec_dim, Stamps& st) {
     radiance = {0.f, 0.f, 0.f};
     if (!hit) {
         F3 bg = background_color<FEAT>(sv, ray);
@@ -1739,7 +1830,8 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
     }
     REGION_BEGIN(surf);
     const DObjRec* ob = sv.objects + h.obj;
-    Surface s;
+    c.ob = ob;
+    Surface& s = c.s;
     surface_at<FEAT>(ob, ray, h.t, h.sub, h.pos, s);
     const bool voxel_mat = (FEAT & FEAT_OCTREE) != 0 && s.voxel >= 0;
     int mkind = ob->mat_kind;
@@ -1751,6 +1843,7 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
     } else if (mkind != MRT_MAT_DIELECTRIC) {
         att = texture_color<FEAT>(sv, ob, s);
     }
+    c.mkind = mkind, c.fuzz = fuzz, c.att = att;
     REGION_END(st, ST_SURFACE, surf);
     // HitRecord::new (hittable.rs:414-448): emit first, else scatter, else nothing.
     switch (mkind) {
@@ -1758,16 +1851,48 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
             if (s.front_face) radiance = thr * att;
             return false;
         }
-        case MAT_VOXEL_VOLUME:      // voxel.rs:90-95: IsotropicPdf (pdf.rs:63-79) with the Lambertian scattering pdf
-        case MRT_MAT_LAMBERTIAN: {  // material.rs:54-64 + ray_tracer.rs:230-268
+        case MAT_VOXEL_VOLUME:  // voxel.rs:90-95: IsotropicPdf (pdf.rs:63-79) with the Lambertian scattering pdf
+            if constexpr ((FEAT & FEAT_VOLUME) != 0) {
+                want_vec = true, vec_dim = MRT_DIM_ISOTROPIC_PDF;
+                return true;
+            }
+            return false;
+        case MRT_MAT_LAMBERTIAN:  // material.rs:54-64 + ray_tracer.rs:230-268
+            lambertian_choose<FEAT>(sv, g, c.lc, want_vec, vec_dim);
+            return true;
+        case MRT_MAT_METAL: {  // material.rs:105-124; also VoxelMaterial::Reflect, voxel.rs:96-115
+            if constexpr ((FEAT & (FEAT_SPECULAR | FEAT_VOLUME)) != 0) {
+                D3 reflected = reflect(normalize(s.dir_obj), s.n_obj);
+                if (!(dot(reflected, s.n_obj) > 0.0)) return false;
+                want_vec = true, vec_dim = MRT_DIM_METAL_FUZZ;
+                return true;
+            }
+            return false;
+        }
+        case MRT_MAT_DIELECTRIC: return (FEAT & FEAT_SPECULAR) != 0;
+        default:  // MRT_MAT_ISOTROPIC, material.rs:274-285
+            want_vec = true, vec_dim = MRT_DIM_ISOTROPIC;
+            return true;
+    }
+}
+// `unit_vec`: rand_unit_vec at the dimensions shade_prepare asked for. `t` = the hit's t.
+template <int FEAT>
+__device__ bool shade_finish(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, double t, const ShadeCtx& c, D3 unit_vec,
+                             uint32_t& light_queries, Stamps& st) {
+    const DObjRec* ob = c.ob;
+    const Surface& s = c.s;
+    const F3 att = c.att;
+    switch (c.mkind) {
+        case MAT_VOXEL_VOLUME:
+        case MRT_MAT_LAMBERTIAN: {
             D3 pos_w = point_to_world(ob, s.pos_obj);
             D3 n_w = normal_to_world(ob, s.n_obj);
             D3 dir;
             double value;
-            if ((FEAT & FEAT_VOLUME) != 0 && mkind == MAT_VOXEL_VOLUME) {
-                dir = rand_unit_vec(g, MRT_DIM_ISOTROPIC_PDF);
+            if ((FEAT & FEAT_VOLUME) != 0 && c.mkind == MAT_VOXEL_VOLUME) {
+                dir = unit_vec;
                 value = 1.0;
-            } else if (!lambertian_generate<FEAT>(sv, s.n_obj, ray.time, pos_w, g, light_queries, dir, value, st)) {
+            } else if (!lambertian_generate<FEAT>(sv, s.n_obj, ray.time, pos_w, g, c.lc, unit_vec, light_queries, dir, value, st)) {
                 return false;
             }
             double cosine = dot(n_w, normalize(dir));  // Lambertian::scattering_pdf_fn, material.rs:30-41
@@ -1776,15 +1901,14 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
             if (scattering_pdf == 0.0) return false;
             float fv = (float)(value * rcp_fast(scattering_pdf));
             thr = {thr.r * att.r / fv, thr.g * att.g / fv, thr.b * att.b / fv};
-            ray = {pos_w, dir, h.t};
+            ray = {pos_w, dir, t};
             break;
         }
-        case MRT_MAT_METAL: {  // material.rs:105-124; the specular ray stays in OBJECT space
-            if constexpr ((FEAT & (FEAT_SPECULAR | FEAT_VOLUME)) != 0) {  // also VoxelMaterial::Reflect, voxel.rs:96-115
+        case MRT_MAT_METAL: {  // the specular ray stays in OBJECT space
+            if constexpr ((FEAT & (FEAT_SPECULAR | FEAT_VOLUME)) != 0) {
                 D3 reflected = reflect(normalize(s.dir_obj), s.n_obj);
-                if (!(dot(reflected, s.n_obj) > 0.0)) return false;
                 thr = thr * att;
-                ray = {s.pos_obj, reflected + fuzz * rand_unit_vec(g, MRT_DIM_METAL_FUZZ), s.time};
+                ray = {s.pos_obj, reflected + c.fuzz * unit_vec, s.time};
                 break;
             }
             return false;
@@ -1815,11 +1939,9 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
             }
             return false;
         }
-        default: {  // MRT_MAT_ISOTROPIC, material.rs:274-285
-            REGION_BEGIN(iso);
+        default: {  // MRT_MAT_ISOTROPIC
             thr = thr * att;
-            ray = {s.pos_obj, rand_unit_vec(g, MRT_DIM_ISOTROPIC), s.time};
-            REGION_END(st, ST_ISOTROPIC, iso);
+            ray = {s.pos_obj, unit_vec, s.time};
             break;
         }
     }
@@ -1829,7 +1951,8 @@ __device__ bool shade_stage(const SceneView& sv, RayD& ray, F3& thr, const Rng& 
 }
 
 // One segment for one lane: nearest hit + material response. `live` marks the lanes that carry a
-// path; with WAVE the traversal is wave-synchronous and every lane of the wave must call this.
+// path; every lane of the wave must call this (the wave-synchronous traversal and the unit-vector
+// sampler are wave-wide).
 template <bool WAVE, int FEAT>
 __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, bool live, F3& radiance,
                              uint32_t& rays, uint32_t& light_queries, Stamps& st, CandLds cand_bits) {
@@ -1843,10 +1966,18 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
         hit = live && nearest_hit_lane<FEAT>(sv, ray, g, h, st, cand_bits);
     }
     REGION_END(st, ST_TRAVERSE, trav);
-    if (!live) return false;
-    rays++;
     REGION_BEGIN(shade);
-    bool cont = shade_stage<FEAT>(sv, ray, thr, g, h, hit, radiance, light_queries, st);
+    ShadeCtx c;
+    bool more = false, want_vec = false, cont = false;
+    uint32_t vec_dim = 0;
+    if (live) {
+        rays++;
+        more = shade_prepare<FEAT>(sv, ray, thr, g, h, hit, radiance, c, want_vec, vec_dim, st);
+    }
+    REGION_BEGIN(uvec);
+    const D3 unit_vec = wave_rand_unit_vec(want_vec, g.base, vec_dim);
+    REGION_END(st, ST_UNIT_VEC, uvec);
+    if (more) cont = shade_finish<FEAT>(sv, ray, thr, g, h.t, c, unit_vec, light_queries, st);
     REGION_END(st, ST_SHADE, shade);
     return cont;
 }
@@ -2225,12 +2356,12 @@ __global__ void __launch_bounds__(BLOCK) k_trace_rays(SceneView sv, const double
 using namespace mrt;
 
 // ---- device memory of mrt_render_accumulate_device_noalloc, the render entry point that allocates
-// nothing: one path pool of NOALLOC_SLOTS slots (3072 waves = three waves per SIMD of a 256-CU GPU,
+// nothing: one path pool of NOALLOC_SLOTS slots (4096 waves = four waves per SIMD of a 256-CU GPU,
 // i.e. one generation of resident waves), the counters and the per-wave work ranges, in a
 // file-scope device array that every GPU the library runs on holds until the process ends.
 // In host code the array's name is only a handle for hipGetSymbolAddress; the address the kernels
 // get is the per-device pointer resolved by resolve_scratch().
-constexpr uint32_t NOALLOC_SLOTS = 3072u * 64u;
+constexpr uint32_t NOALLOC_SLOTS = 4096u * 64u;
 constexpr size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
 struct ScratchLayout {
     size_t pool, counters, wave_chunks, total;
@@ -2673,7 +2804,7 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
 #ifdef MRT_STAMPS
     {
         static const char* names[ST_COUNT] = {"regen", "traverse(all)", "  leaf:solid", "surface+texture", "lambert:generate",
-                                              "lambert:light value", "shade(all)", "accumulate", "total", "  leaf:medium", "  regen:claim", "  gen:cosine", "  gen:light", "  gen:sky", "isotropic scatter", "  candidate search"};
+                                              "lambert:light value", "shade(all)", "accumulate", "total", "  leaf:medium", "  regen:claim", "  gen:cosine", "  gen:light", "  gen:sky", "unit vectors (wave)", "  candidate search"};
         std::fprintf(stderr, "[stamps] candidate search per query: %.1f spatial nodes, %.1f marked inner nodes, %.1f marked leaves (%llu queries)\n",
                      (double)host.stamp_counts[0] / (double)std::max(1ull, host.stamp_counts[3]),
                      (double)host.stamp_counts[1] / (double)std::max(1ull, host.stamp_counts[3]),
