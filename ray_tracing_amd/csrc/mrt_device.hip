@@ -62,6 +62,16 @@ struct SceneView {
     mrt_background bg;
     mrt_sun sun;
 };
+#define CONST_AS __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const CONST_AS T* as_const(const T* p) {
+    return (const CONST_AS T*)p;
+}
+// The kernels get the scene view as a pointer to a copy in device memory and read it through the constant
+// address space: a field is a scalar load where it is used. Passed by value, its 110 dwords were loaded into
+// SGPRs at kernel entry, stayed live across the whole segment loop and were spilled into VGPR lanes, so that
+// every use cost vector instructions (v_readlane) to get the value back.
+using SceneRef = const CONST_AS SceneView&;
 
 // The path pool: ONE block of memory holding, for `cap` slots, seven f64 arrays (ray origin, direction,
 // time), the RNG keys, three f32 arrays (throughput), the pixel indices and the segment counters. A kernel
@@ -218,7 +228,8 @@ __device__ __forceinline__ D3 normalize(D3 a) {
 }
 constexpr double INV_PI = 0.31830988618379067154;
 __device__ __forceinline__ double comp(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
-__device__ __forceinline__ D3 ld3(const double* p) { return {p[0], p[1], p[2]}; }
+template <class P>
+__device__ __forceinline__ D3 ld3(P p) { return {p[0], p[1], p[2]}; }
 
 struct RayD {
     D3 o, d;
@@ -335,11 +346,6 @@ __device__ D3 wave_rand_unit_vec(bool want, uint64_t rng_base, uint32_t dim_base
 // Scene records are read through two kinds of pointers: ordinary global pointers when the
 // index differs per lane, and constant-address-space pointers (CONST_AS) when the index is the
 // same for the whole wave, so that the loads become scalar loads and the values live in SGPRs.
-#define CONST_AS __attribute__((address_space(4)))
-template <class T>
-__device__ __forceinline__ const CONST_AS T* as_const(const T* p) {
-    return (const CONST_AS T*)p;
-}
 
 // ============================================================== transforms (hittable.rs:92-107)
 // The functions of the nearest-hit query below (transforms, shape and box tests) spell out their
@@ -801,7 +807,7 @@ __device__ bool octree_hit(const DOctNode* nodes, const mrt_voxel* voxels, const
 // The boundary queries of a medium and the plain query of a solid share ONE copy of the shape
 // code (a loop of one or two rounds), which keeps the kernel's instruction footprint small.
 template <int FEAT, class PP, class AP>
-__device__ __forceinline__ bool leaf_hit(const SceneView& sv, int kind, int bkind, int octree, PP p,
+__device__ __forceinline__ bool leaf_hit(SceneRef sv, int kind, int bkind, int octree, PP p,
                                          double neg_inv_density, bool identity, AP to_object, const RayD& ray,
                                          D3 inv_world, double t_min, double t_max, const Rng& g, uint32_t medium_dim,
                                          uint32_t& oct_entry, double& t, int& sub, D3& pos, bool translation = false) {
@@ -864,7 +870,7 @@ __device__ __forceinline__ bool leaf_hit(const SceneView& sv, int kind, int bkin
 }
 // Leaf test from an object record.
 template <int FEAT, class OP>
-__device__ __forceinline__ bool object_hit(const SceneView& sv, OP ob, const RayD& ray, D3 inv_world, double t_min,
+__device__ __forceinline__ bool object_hit(SceneRef sv, OP ob, const RayD& ray, D3 inv_world, double t_min,
                                            double t_max, const Rng& g, uint32_t medium_dim, uint32_t& oct_entry, double& t,
                                            int& sub, D3& pos) {
     return leaf_hit<FEAT>(sv, ob->kind, ob->gkind, ob->octree, &ob->p[0], ob->p[9], ob->identity != 0, &ob->to_object, ray,
@@ -872,7 +878,7 @@ __device__ __forceinline__ bool object_hit(const SceneView& sv, OP ob, const Ray
 }
 // Leaf test of the wave-synchronous walk from a self-contained node record (scalar operands).
 template <int FEAT, class RP>
-__device__ __forceinline__ bool node_hit(const SceneView& sv, RP r, const RayD& ray, D3 inv_world, double t_min,
+__device__ __forceinline__ bool node_hit(SceneRef sv, RP r, const RayD& ray, D3 inv_world, double t_min,
                                          double t_max, const Rng& g, uint32_t medium_dim, uint32_t& oct_entry, double& t,
                                          int& sub, D3& pos) {
     return leaf_hit<FEAT>(sv, r->kind, r->kind2, r->octree, &r->p[0], r->p[9], r->identity != 0, &r->to_object, ray,
@@ -922,7 +928,7 @@ struct LaneWalk {
 // The leaf's shape record `lr` comes with the node (same index, requested together with it), so a visit
 // costs one round trip to memory; the object record itself is only touched for objects with a transform.
 template <int FEAT>
-__device__ __forceinline__ bool lane_visit(const SceneView& sv, const DNode& nd, const DLeafRec& lr, const RayD& ray, D3 inv_d,
+__device__ __forceinline__ bool lane_visit(SceneRef sv, const DNode& nd, const DLeafRec& lr, const RayD& ray, D3 inv_d,
                                            const Rng& g, LaneWalk& w) {
     const double t_min = (double)0.001f;
     const int obj = nd.object;
@@ -974,7 +980,7 @@ struct CandLds {
 // ancestors; phase 2 is the reference's walk over the marked nodes (ascending index =
 // pre-order), with the walk's own node code. Gives the walk's result.
 template <int FEAT>
-__device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, const Rng& g, HitD& out, CandLds lds,
+__device__ bool nearest_hit_candidates(SceneRef sv, const RayD& ray, const Rng& g, HitD& out, CandLds lds,
                                        Stamps& st) {
     D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
     LDS_AS uint32_t* bits = lds.bits;
@@ -1131,7 +1137,7 @@ __device__ bool nearest_hit_candidates(const SceneView& sv, const RayD& ray, con
     return w.best_obj >= 0;
 }
 template <int FEAT>
-__device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng& g, HitD& out, Stamps& st,
+__device__ bool nearest_hit_lane(SceneRef sv, const RayD& ray, const Rng& g, HitD& out, Stamps& st,
                                  CandLds lds = CandLds{nullptr, nullptr, 0}) {
     // (a zero or non-finite direction component makes slab bounds undefined: those rays take the walk)
     const double dmin = fmin(fabs(ray.d.x), fmin(fabs(ray.d.y), fabs(ray.d.z)));
@@ -1162,7 +1168,7 @@ __device__ bool nearest_hit_lane(const SceneView& sv, const RayD& ray, const Rng
 // (`resume`); a subtree no lane wants is skipped for the whole wave by a ballot. Must be called
 // by every lane of the wave; lanes with live == false only follow along.
 template <int FEAT>
-__device__ bool nearest_hit_wave(const SceneView& sv, const RayD& ray, const Rng& g, bool live, HitD& out, Stamps& st) {
+__device__ bool nearest_hit_wave(SceneRef sv, const RayD& ray, const Rng& g, bool live, HitD& out, Stamps& st) {
     const double t_min = (double)0.001f;
     double closest = (double)FLT_MAX;
     int best_obj = -1, best_sub = 0;
@@ -1366,7 +1372,7 @@ __device__ __forceinline__ uint32_t f64_as_index(double v, uint32_t hi) {  // Ru
     return (uint32_t)v;
 }
 template <int FEAT>
-__device__ F3 texture_color(const SceneView& sv, const DObjRec* sh, const Surface& sf) {
+__device__ F3 texture_color(SceneRef sv, const DObjRec* sh, const Surface& sf) {
     // SolidColor textures are folded into the object record
     if ((FEAT & FEAT_TEXTURE) == 0 || sh->tex_solid) return {sh->color[0], sh->color[1], sh->color[2]};
     const int tex = sh->texture;
@@ -1552,7 +1558,7 @@ __device__ void object_generate(OP ob, D3 origin, double time, const Rng& g, dou
 
 // LightPdf::value, pdf.rs:82-99 with World::nearest_light_hit, world.rs:98-110. Returns false for None.
 template <int FEAT>
-__device__ bool light_pdf_value(const SceneView& sv, const RayD& ray, const Rng& g, uint32_t& light_queries,
+__device__ bool light_pdf_value(SceneRef sv, const RayD& ray, const Rng& g, uint32_t& light_queries,
                                 double& value) {
     constexpr int LF = FEAT & ~(FEAT_OCTREE | FEAT_VOLUME);  // an octree is never a light
     light_queries++;
@@ -1607,7 +1613,8 @@ __device__ __forceinline__ Onb onb_from_w(D3 n) {
     D3 u = cross(w, v);
     return {u, v, w};
 }
-__device__ __forceinline__ D3 sun_direction(const mrt_sun& s) {  // sun.rs:17-20
+template <class S>
+__device__ __forceinline__ D3 sun_direction(const S& s) {  // sun.rs:17-20
     double r = cos(s.phi);
     return {r * cos(s.theta), sin(s.phi), r * sin(s.theta)};
 }
@@ -1621,7 +1628,7 @@ struct LambertChoice {
     double ua, ub;
 };
 template <int FEAT>
-__device__ __forceinline__ void lambertian_choose(const SceneView& sv, const Rng& g, LambertChoice& c, bool& want_vec,
+__device__ __forceinline__ void lambertian_choose(SceneRef sv, const Rng& g, LambertChoice& c, bool& want_vec,
                                                   uint32_t& vec_dim) {
     const uint32_t r = rand_u32(g, 0, 3, MRT_DIM_PDF_CHOICE);
     // Every branch starts with two uniforms (cosine lobe: r1, r2; light: the two coordinates on a
@@ -1648,7 +1655,7 @@ __device__ __forceinline__ void lambertian_choose(const SceneView& sv, const Rng
 }
 // Returns false for None. `unit_vec`: what rand_unit_vec gives at the dimensions lambertian_choose asked for.
 template <int FEAT>
-__device__ bool lambertian_generate(const SceneView& sv, D3 pdf_normal, double incoming_time, D3 hit_point,
+__device__ bool lambertian_generate(SceneRef sv, D3 pdf_normal, double incoming_time, D3 hit_point,
                                     const Rng& g, const LambertChoice& c, D3 unit_vec, uint32_t& light_queries, D3& out_dir,
                                     double& out_value, Stamps& st) {
     REGION_BEGIN(gen);
@@ -1735,8 +1742,8 @@ __device__ __forceinline__ F3 sky_color(double intensity, const RayD& ray) {  //
     return {c.r * k, c.g * k, c.b * k};
 }
 template <int FEAT>
-__device__ F3 background_color(const SceneView& sv, const RayD& ray) {
-    const mrt_background& b = sv.bg;
+__device__ F3 background_color(SceneRef sv, const RayD& ray) {
+    const auto& b = sv.bg;
     if ((FEAT & FEAT_SKY) == 0 || b.kind == MRT_BG_CONSTANT) return {b.color[0], b.color[1], b.color[2]};  // constant_color.rs:12-14
     if (b.kind == MRT_BG_SUN_SKY) {  // sun_sky.rs:32-60
         double r = cos(b.sun_phi);
@@ -1751,9 +1758,9 @@ __device__ F3 background_color(const SceneView& sv, const RayD& ray) {
 }
 
 // ============================================================== camera (camera.rs:88-106, ray_tracer.rs:444-447)
-__device__ RayD camera_ray(const SceneView& sv, uint32_t x, uint32_t y, uint32_t width, uint32_t height,
+__device__ RayD camera_ray(SceneRef sv, uint32_t x, uint32_t y, uint32_t width, uint32_t height,
                            const Rng& g) {
-    const DCamera& c = sv.cam;
+    const auto& c = sv.cam;
     double s = ((double)x + rand_scalar(g, 0.0, 1.0, MRT_DIM_JITTER_U)) / ((double)width - 1.0);
     double t = ((double)y + rand_scalar(g, 0.0, 1.0, MRT_DIM_JITTER_V)) / ((double)height - 1.0);
     D3 p{0.0, 0.0, 0.0};
@@ -1788,7 +1795,7 @@ __device__ __forceinline__ D3 reflect(D3 v, D3 n) { return v - 2.0 * dot(v, n) *
 // Lambertian -> LAMBERTIAN, Reflect -> METAL with the voxel's fuzz, Volume -> MAT_VOXEL_VOLUME.
 constexpr int MAT_VOXEL_VOLUME = 100;
 template <int FEAT>
-__device__ __forceinline__ int voxel_material(const SceneView& sv, const Surface& s, F3& att, double& fuzz) {
+__device__ __forceinline__ int voxel_material(SceneRef sv, const Surface& s, F3& att, double& fuzz) {
     const mrt_voxel& vx = sv.oct_voxels[s.voxel];
     att = {vx.albedo[0], vx.albedo[1], vx.albedo[2]};
     fuzz = 0.0;
@@ -1820,7 +1827,7 @@ struct ShadeCtx {
     LambertChoice lc;
 };
 template <int FEAT>
-__device__ bool shade_prepare(const SceneView& sv, const RayD& ray, const F3& thr, const Rng& g, const HitD& h, bool hit,
+__device__ bool shade_prepare(SceneRef sv, const RayD& ray, const F3& thr, const Rng& g, const HitD& h, bool hit,
                               F3& radiance, ShadeCtx& c, bool& want_vec, uint32_t& vec_dim, Stamps& st) {
     radiance = {0.f, 0.f, 0.f};
     if (!hit) {
@@ -1877,7 +1884,7 @@ __device__ bool shade_prepare(const SceneView& sv, const RayD& ray, const F3& th
 }
 // `unit_vec`: rand_unit_vec at the dimensions shade_prepare asked for. `t` = the hit's t.
 template <int FEAT>
-__device__ bool shade_finish(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, double t, const ShadeCtx& c, D3 unit_vec,
+__device__ bool shade_finish(SceneRef sv, RayD& ray, F3& thr, const Rng& g, double t, const ShadeCtx& c, D3 unit_vec,
                              uint32_t& light_queries, Stamps& st) {
     const DObjRec* ob = c.ob;
     const Surface& s = c.s;
@@ -1954,7 +1961,7 @@ __device__ bool shade_finish(const SceneView& sv, RayD& ray, F3& thr, const Rng&
 // path; every lane of the wave must call this (the wave-synchronous traversal and the unit-vector
 // sampler are wave-wide).
 template <bool WAVE, int FEAT>
-__device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng& g, bool live, F3& radiance,
+__device__ bool path_segment(SceneRef sv, RayD& ray, F3& thr, const Rng& g, bool live, F3& radiance,
                              uint32_t& rays, uint32_t& light_queries, Stamps& st, CandLds cand_bits) {
     radiance = {0.f, 0.f, 0.f};
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
@@ -1984,7 +1991,7 @@ __device__ bool path_segment(const SceneView& sv, RayD& ray, F3& thr, const Rng&
 
 // ============================================================== kernels
 // This lane's columns of the workgroup's candidate-search arrays (nearest_hit_candidates), bits cleared.
-__device__ __forceinline__ CandLds candidate_lds(const SceneView& sv) {
+__device__ __forceinline__ CandLds candidate_lds(SceneRef sv) {
     const uint32_t tpb = blockDim.x;
     uint32_t* base = dynamic_lds();
     CandLds lds{(LDS_AS uint32_t*)base + threadIdx.x, (LDS_AS uint16_t*)(base + CAND_WORDS * tpb) + threadIdx.x, tpb};
@@ -2028,8 +2035,9 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 // One launch = up to `steps` segments for every slot of the pool.
 template <bool WAVE, int FEAT>
-__global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segments(SceneView sv, Pool pool, RenderParams rp,
+__global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segments(const SceneView* svp, Pool pool, RenderParams rp,
                                                                                Counters* ctr, unsigned long long* wave_chunks) {
+    SceneRef sv = *as_const(svp);
     const uint32_t slot = blockIdx.x * seg_block(WAVE) + threadIdx.x;
     const bool in_range = slot < rp.n_slots;
     int32_t seg = -1;
@@ -2174,7 +2182,7 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
 // DiffuseShader::ray_color (ray_tracer.rs:126-157): what HitRecord::new (hittable.rs:414-448) decides
 // for the nearest hit -- emitted colour, scatter attenuation, or black -- or the background.
 template <int FEAT>
-__device__ F3 diffuse_stage(const SceneView& sv, const RayD& ray, const HitD& h, bool hit) {
+__device__ F3 diffuse_stage(SceneRef sv, const RayD& ray, const HitD& h, bool hit) {
     if (!hit) return background_color<FEAT>(sv, ray);
     const DObjRec* ob = sv.objects + h.obj;
     Surface s;
@@ -2207,8 +2215,9 @@ __device__ F3 diffuse_stage(const SceneView& sv, const RayD& ray, const HitD& h,
 // sampled point and one more nearest-hit query per light (LightMapShader::ray_color,
 // ray_tracer.rs:83-124; segment 1 + i addresses the random numbers of light i).
 template <bool WAVE, int FEAT, int MODE>
-__global__ void __launch_bounds__(BLOCK) k_single_bounce(SceneView sv, RenderParams rp, unsigned long long w_begin,
+__global__ void __launch_bounds__(BLOCK) k_single_bounce(const SceneView* svp, RenderParams rp, unsigned long long w_begin,
                                                          unsigned long long w_end, Counters* ctr) {
+    SceneRef sv = *as_const(svp);
     const unsigned long long w = w_begin + (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
     const bool live = w < w_end;
     RayD ray{{0, 0, 0}, {0, 0, 1}, 0};
@@ -2305,9 +2314,10 @@ __global__ void __launch_bounds__(BLOCK) k_compact(Pool src, Pool dst, uint32_t 
 }
 
 // Probe kernels (parity tests).
-__global__ void __launch_bounds__(BLOCK) k_camera_rays(SceneView sv, uint32_t width, uint32_t height,
+__global__ void __launch_bounds__(BLOCK) k_camera_rays(const SceneView* svp, uint32_t width, uint32_t height,
                                                        const int32_t* pixels, uint32_t n, uint64_t seed,
                                                        uint64_t sample, double* out) {
+    SceneRef sv = *as_const(svp);
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     uint32_t x = (uint32_t)pixels[2 * i], y = (uint32_t)pixels[2 * i + 1];
@@ -2317,9 +2327,10 @@ __global__ void __launch_bounds__(BLOCK) k_camera_rays(SceneView sv, uint32_t wi
     o[0] = r.o.x, o[1] = r.o.y, o[2] = r.o.z, o[3] = r.d.x, o[4] = r.d.y, o[5] = r.d.z, o[6] = r.time;
 }
 template <bool WAVE, int FEAT>
-__global__ void __launch_bounds__(BLOCK) k_trace_rays(SceneView sv, const double* rays, uint32_t n, uint64_t seed,
+__global__ void __launch_bounds__(BLOCK) k_trace_rays(const SceneView* svp, const double* rays, uint32_t n, uint64_t seed,
                                                       int32_t* obj_id, double* t_out, double* normal,
                                                       double* position, int32_t* front_face) {
+    SceneRef sv = *as_const(svp);
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     const bool live = i < n;
     RayD ray{{0, 0, 0}, {0, 0, 1}, 0};
@@ -2448,6 +2459,9 @@ struct mrt_scene {
     int64_t opt_traversal = 0;  // 0 auto, 1 per-lane, 2 wave-synchronous over the tree, 3 over the leaf list, 4 candidates
     const DNodeRec* dev_node_recs = nullptr;
     const DNodeRec* dev_leaf_recs = nullptr;
+    // what the kernels get: device copies of the view, one per traversal mode and setting of
+    // "trace_zero_throughput" (device_view), written when the scene is created
+    SceneView* dev_views = nullptr;
     int features = 0;           // FEAT_* bits the scene needs
     // per-scene call resources, created with the scene so that a render call creates nothing:
     // events (whole call begin / end, segment kernel begin / end) and a pinned host copy of the counters
@@ -2555,7 +2569,19 @@ int upload_scene(mrt_scene* sc) {
     v.bg = f.background;
     v.sun = f.sun;
     v.trace_zero_throughput = 0;
+    if ((rc = m.alloc(sizeof(SceneView) * 2 * TRAV_CANDIDATES, reinterpret_cast<void**>(&sc->dev_views))) != MRT_OK) return rc;
+    for (int mode = TRAV_LANE; mode <= TRAV_CANDIDATES; ++mode) {
+        for (int tz = 0; tz < 2; ++tz) {
+            SceneView dv = view_for(sc, mode);
+            dv.trace_zero_throughput = tz;
+            HIP_TRY(hipMemcpy(sc->dev_views + (mode - 1) * 2 + tz, &dv, sizeof(SceneView), hipMemcpyHostToDevice));
+        }
+    }
     return MRT_OK;
+}
+// The device copy of view_for(sc, mode) with "trace_zero_throughput" set as given.
+const SceneView* device_view(const mrt_scene* sc, int mode, bool trace_zero) {
+    return sc->dev_views + (mode - 1) * 2 + (trace_zero ? 1 : 0);
 }
 
 int ensure_pool(mrt_scene* sc) {
@@ -2688,8 +2714,7 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
         rp.chunk = per_wave >= WORK_CHUNK ? WORK_CHUNK : (per_wave <= 64 ? 64u : (uint32_t)(per_wave & ~63ull));
     }
     const int trav = traversal_mode(sc);
-    SceneView view = view_for(sc, trav);
-    view.trace_zero_throughput = (int32_t)sc->opt_trace_zero;
+    const SceneView* view = device_view(sc, trav, sc->opt_trace_zero != 0);
     const bool wave_sync = trav != TRAV_LANE && trav != TRAV_CANDIDATES;
 
     HIP_TRY(hipEventRecord(ev_begin, stream));
@@ -3135,7 +3160,8 @@ int mrt_camera_rays(mrt_scene* scene, uint32_t width, uint32_t height, const int
     if ((rc = tmp.alloc(sizeof(int32_t) * 2 * n, (void**)&dpix)) != MRT_OK) return rc;
     if ((rc = tmp.alloc(sizeof(double) * 7 * n, (void**)&dout)) != MRT_OK) return rc;
     HIP_TRY(hipMemcpy(dpix, pixels, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_camera_rays, dim3(((uint32_t)n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0, scene->view, width,
+    hipLaunchKernelGGL(k_camera_rays, dim3(((uint32_t)n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, 0,
+                       device_view(scene, traversal_mode(scene), false), width,
                        height, dpix, (uint32_t)n, seed, sample_index, dout);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(rays_out, dout, sizeof(double) * 7 * n, hipMemcpyDeviceToHost));
@@ -3165,7 +3191,7 @@ int mrt_trace_rays(mrt_scene* scene, const double* rays, size_t n, uint64_t seed
         const dim3 grid(((uint32_t)n + BLOCK - 1) / BLOCK), block(BLOCK);
         const int trav = traversal_mode(scene);
         const bool ws = trav != TRAV_LANE && trav != TRAV_CANDIDATES;
-        const SceneView view = view_for(scene, trav);
+        const SceneView* view = device_view(scene, trav, false);
         dispatch_feat(scene->features, KernelFeats{}, [&](auto feat) {
             constexpr int FT = decltype(feat)::value;
             if (ws)
