@@ -2018,13 +2018,21 @@ constexpr size_t lds_bytes(bool wave, int feat, int threads) {
 #ifndef MRT_LEAN_WAVES
 #define MRT_LEAN_WAVES 4
 #endif
+#ifndef MRT_HEAVY_WAVES
+#define MRT_HEAVY_WAVES 3
+#endif
+#ifndef MRT_OCTREE_WAVES
+#define MRT_OCTREE_WAVES 3
+#endif
 constexpr int seg_waves(bool wave, int feat) {
     if (!wave) return MRT_LANE_WAVES;
-    // measured per feature set (with the loop's constants and arguments no longer hoisted into registers): the
-    // lean kernels without octree code gain from a fourth wave (Cornell smoke +6 %, Easy Cornell Box +5 %), the
-    // octree walk loses a third of its speed to the spills of 128 registers, the kernels with specular materials
-    // and textures fit three waves now (Easy Scene +19 %)
-    return (feat & (FEAT_SPECULAR | FEAT_TEXTURE | FEAT_OCTREE)) != 0 ? 3 : MRT_LEAN_WAVES;
+    // measured per feature set (with the loop's constants and arguments no longer hoisted into registers, and the
+    // scene view read through a pointer): the wave-synchronous kernels without octree code gain from a fourth wave
+    // (Cornell smoke +6 %, Easy Cornell Box +5 %, Light Demonstration +9 %) except the set with everything
+    // (Perlin noise, media: Easy Scene -1.4 %); the octree walk loses a third of its speed to the spills of 128
+    // registers
+    if ((feat & FEAT_OCTREE) != 0) return MRT_OCTREE_WAVES;
+    return (feat & FEAT_PERLIN) != 0 ? MRT_HEAVY_WAVES : MRT_LEAN_WAVES;
 }
 
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
