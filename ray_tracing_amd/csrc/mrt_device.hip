@@ -114,7 +114,7 @@ struct Counters {
     unsigned long long held;  // work items claimed by waves but not started when the launch ended
     unsigned long long stamps[ST_COUNT];  // diagnostic build only
     unsigned long long stamp_lanes[ST_COUNT];
-    unsigned long long stamp_counts[4];
+    unsigned long long stamp_counts[8];
 };
 
 // Diagnostic build (-DMRT_STAMPS): wave-level cycle shares of the segment kernel's regions.
@@ -124,9 +124,10 @@ struct Counters {
 struct Stamps {
     unsigned long long acc[ST_COUNT];
     unsigned long long lanes[ST_COUNT];  // cycles x active lanes (lane utilisation of the region)
-    unsigned int count[4];               // per-lane event counts of the candidate search
+    unsigned int count[8];               // event counts of the candidate search: 0-3 per lane, 4-6 per wave (rounds, queries)
 };
 #define STAMP_COUNT(st, i) ((st).count[i]++)
+#define STAMP_COUNT_WAVE(st, i) ((st).count[i] += (__lane_id() == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) ? 1u : 0u)
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);
@@ -144,6 +145,7 @@ __device__ __forceinline__ void stamp_add(Stamps& st, int i, unsigned long long 
 #else
 struct Stamps {};
 #define STAMP_COUNT(st, i) ((void)0)
+#define STAMP_COUNT_WAVE(st, i) ((void)0)
 #define REGION_BEGIN(name) ((void)0)
 #define REGION_END(st, i, name) ((void)0)
 #endif
@@ -964,113 +966,145 @@ __device__ __forceinline__ bool lane_visit(SceneRef sv, const DNode& nd, const D
 // Per-ray constants of the candidate search's slab tests: t = bound * inv - origin * inv.
 struct CandRay {
     double inv[3], oi[3];
-    double tau;
-    int neg;  // tau < 0: selects the velocity bounds that give the lower / upper corner
+    double tau;  // the ray's time
 };
 #define LDS_AS __attribute__((address_space(3)))
-// Per-lane LDS state of the candidate search: a [CAND_WORDS][BLOCK] bit array, one bit per tree
-// node, all zero between queries, and a [CAND_STACK][BLOCK] node stack (columns of this lane).
+// LDS state of the candidate search. Per lane (columns of [row][threads per workgroup] arrays): a bit per
+// tree node, all zero between queries, in rows 0 .. CAND_WORDS - 1, and in row CAND_WORDS one bit per row
+// that holds marks. Per wave: the work queue of the spatial search, CAND_QUEUE entries.
 struct CandLds {
-    LDS_AS uint32_t* bits;
-    LDS_AS uint16_t* stack;
-    uint32_t stride;  // threads per workgroup
+    LDS_AS uint32_t* bits;   // this lane's column
+    LDS_AS uint16_t* queue;  // this wave's queue
+    uint32_t stride;         // threads per workgroup
 };
-// Candidate search for large trees (host side: build_candidate_tree). Phase 1 walks the spatial
-// tree and marks every leaf whose tight box the ray's line meets, together with the leaf's
-// ancestors; phase 2 is the reference's walk over the marked nodes (ascending index =
-// pre-order), with the walk's own node code. Gives the walk's result.
-template <int FEAT>
-__device__ bool nearest_hit_candidates(SceneRef sv, const RayD& ray, const Rng& g, HitD& out, CandLds lds,
-                                       Stamps& st) {
-    D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
-    LDS_AS uint32_t* bits = lds.bits;
-    uint32_t touched = 0;  // which words of the bit array hold marks (CAND_WORDS <= 32)
-    static_assert(CAND_WORDS <= 32, "one summary bit per word");
-    const CandRay cr{{inv_d.x, inv_d.y, inv_d.z}, {ray.o.x * inv_d.x, ray.o.y * inv_d.y, ray.o.z * inv_d.z}, ray.time,
-                     ray.time < 0.0 ? 1 : 0};
-    REGION_BEGIN(search);
-    {
-        int sp = 0;
-        int node = 0;
-        for (;;) {
-            // One node = one batch of independent loads (the whole first line, then the velocity line of a
-            // node with moving children), requested before anything is tested: a lane's walk is a chain of
-            // dependent node fetches, and a load issued inside a per-child branch would add its own
-            // round trip to that chain.
-            const DCand4* nd = sv.cand_nodes + node;
-            const int4 ch4 = *reinterpret_cast<const int4*>(nd->child);
-            float4 lo4[3], hi4[3];
+constexpr int CAND_QUEUE = CAND_STACK * 64;
+// Phase 1 of the candidate search for all lanes of a wave at once (`asking` lanes bring the ray constants
+// `cr`): walks the spatial tree and marks, in the asking lane's bit column, every leaf whose box the ray's line
+// meets. A lane walking alone visits 6.4 nodes of the random-spheres tree on average, but the wave waits for
+// its longest walk, 14.5 rounds. Which leaves get marked does not depend on the order of the visits, so the
+// visits of all lanes go through one queue of (lane, node) entries per wave and every round the 64 lanes take
+// the 64 newest entries, whoever's they are: a lane fetches the constants of the ray it works for from that
+// ray's lane (ds_bpermute), tests the node's four children, ORs leaf marks into that lane's column and the
+// wave appends the inner children that were hit. Returns false when the queue could overflow (the marks are
+// incomplete then; the caller clears them and takes the plain walk). Every lane of the wave must call this.
+__device__ bool wave_candidate_search(SceneRef sv, const CandRay& cr, bool asking, CandLds lds, Stamps& st) {
+    const uint32_t lane = __lane_id();
+    LDS_AS uint16_t* queue = lds.queue;
+    LDS_AS uint32_t* column0 = lds.bits - lane;  // column of lane 0 of this wave
+    const unsigned long long ask = __ballot(asking);
+    uint32_t n_items = (uint32_t)__popcll(ask);  // wave-uniform
+    if (asking)  // every asking lane starts at the root (node 0)
+        queue[__builtin_amdgcn_mbcnt_hi((uint32_t)(ask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ask, 0u))] = (uint16_t)(lane << 10);
+    bool complete = true;
+    while (n_items > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t take = n_items < 64u ? n_items : 64u;
+        if (n_items + 3u * take > (uint32_t)CAND_QUEUE) {
+            complete = false;
+            break;
+        }
+        const bool work = lane < take;
+        uint32_t item = 0;
+        if (work) item = queue[n_items - 1u - lane];
+        n_items -= take;
+        const uint32_t owner = item >> 10, node = item & 1023u;
+        // One node = one batch of independent loads (the whole first line, then the velocity line of a
+        // node with moving children), requested before anything is tested: a load issued inside a
+        // per-child branch would add its own round trip to the chain of node fetches.
+        const DCand4* nd = sv.cand_nodes + node;
+        const int4 ch4 = *reinterpret_cast<const int4*>(nd->child);
+        float4 lo4[3], hi4[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo4[a] = *reinterpret_cast<const float4*>(nd->lo[a]);
+            hi4[a] = *reinterpret_cast<const float4*>(nd->hi[a]);
+        }
+        const bool moving = nd->moving != 0;
+        // the constants of the ray this lane works for
+        const int from = (int)owner;
+        const double inv[3] = {__shfl(cr.inv[0], from, 64), __shfl(cr.inv[1], from, 64), __shfl(cr.inv[2], from, 64)};
+        const double oi[3] = {__shfl(cr.oi[0], from, 64), __shfl(cr.oi[1], from, 64), __shfl(cr.oi[2], from, 64)};
+        const double tau = __shfl(cr.tau, from, 64);
+        if (work) STAMP_COUNT(st, 0);
+        STAMP_COUNT_WAVE(st, 4);
+        double bl[3][4], bh[3][4];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            bl[a][0] = (double)lo4[a].x, bl[a][1] = (double)lo4[a].y, bl[a][2] = (double)lo4[a].z, bl[a][3] = (double)lo4[a].w;
+            bh[a][0] = (double)hi4[a].x, bh[a][1] = (double)hi4[a].y, bh[a][2] = (double)hi4[a].z, bh[a][3] = (double)hi4[a].w;
+        }
+        if (moving) {
+            // tau >= 0: the lower corner moves with the smallest velocity, the upper with the largest; tau < 0: swapped
+            const bool neg = tau < 0.0;
+            const float(*v_for_lo)[4] = neg ? nd->vhi : nd->vlo;
+            const float(*v_for_hi)[4] = neg ? nd->vlo : nd->vhi;
+            float4 vl4[3], vh4[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                lo4[a] = *reinterpret_cast<const float4*>(nd->lo[a]);
-                hi4[a] = *reinterpret_cast<const float4*>(nd->hi[a]);
+                vl4[a] = *reinterpret_cast<const float4*>(v_for_lo[a]);
+                vh4[a] = *reinterpret_cast<const float4*>(v_for_hi[a]);
             }
-            const bool moving = nd->moving != 0;
-            STAMP_COUNT(st, 0);
-            double bl[3][4], bh[3][4];
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                bl[a][0] = (double)lo4[a].x, bl[a][1] = (double)lo4[a].y, bl[a][2] = (double)lo4[a].z, bl[a][3] = (double)lo4[a].w;
-                bh[a][0] = (double)hi4[a].x, bh[a][1] = (double)hi4[a].y, bh[a][2] = (double)hi4[a].z, bh[a][3] = (double)hi4[a].w;
+                bl[a][0] = fma(tau, (double)vl4[a].x, bl[a][0]), bl[a][1] = fma(tau, (double)vl4[a].y, bl[a][1]);
+                bl[a][2] = fma(tau, (double)vl4[a].z, bl[a][2]), bl[a][3] = fma(tau, (double)vl4[a].w, bl[a][3]);
+                bh[a][0] = fma(tau, (double)vh4[a].x, bh[a][0]), bh[a][1] = fma(tau, (double)vh4[a].y, bh[a][1]);
+                bh[a][2] = fma(tau, (double)vh4[a].z, bh[a][2]), bh[a][3] = fma(tau, (double)vh4[a].w, bh[a][3]);
             }
-            if (moving) {
-                // tau >= 0: the lower corner moves with the smallest velocity, the upper with the largest; tau < 0: swapped
-                const float(*v_for_lo)[4] = cr.neg ? nd->vhi : nd->vlo;
-                const float(*v_for_hi)[4] = cr.neg ? nd->vlo : nd->vhi;
-                float4 vl4[3], vh4[3];
+        }
+        const int child[4] = {ch4.x, ch4.y, ch4.z, ch4.w};
+        LDS_AS uint32_t* column = column0 + owner;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    vl4[a] = *reinterpret_cast<const float4*>(v_for_lo[a]);
-                    vh4[a] = *reinterpret_cast<const float4*>(v_for_hi[a]);
-                }
+        for (int k = 0; k < 4; ++k) {
+            // whether the ray's line over [0.001, FLT_MAX] can meet the box of child k at the ray's time (all
+            // three slabs jointly); an absent child has an inside-out box (lo = inf, hi = -inf) and never passes
+            double lo = (double)0.001f, hi = (double)FLT_MAX;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    bl[a][0] = fma(cr.tau, (double)vl4[a].x, bl[a][0]), bl[a][1] = fma(cr.tau, (double)vl4[a].y, bl[a][1]);
-                    bl[a][2] = fma(cr.tau, (double)vl4[a].z, bl[a][2]), bl[a][3] = fma(cr.tau, (double)vl4[a].w, bl[a][3]);
-                    bh[a][0] = fma(cr.tau, (double)vh4[a].x, bh[a][0]), bh[a][1] = fma(cr.tau, (double)vh4[a].y, bh[a][1]);
-                    bh[a][2] = fma(cr.tau, (double)vh4[a].z, bh[a][2]), bh[a][3] = fma(cr.tau, (double)vh4[a].w, bh[a][3]);
-                }
+            for (int a = 0; a < 3; ++a) {
+                const double t0 = fma(bl[a][k], inv[a], -oi[a]), t1 = fma(bh[a][k], inv[a], -oi[a]);
+                lo = fmax(lo, fmin(t0, t1)), hi = fmin(hi, fmax(t0, t1));
             }
-            const int child[4] = {ch4.x, ch4.y, ch4.z, ch4.w};
-            bool meets[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                // whether the ray's line over [0.001, FLT_MAX] can meet the box of child k at the ray's time (all
-                // three slabs jointly); an absent child has an inside-out box (lo = inf, hi = -inf) and never passes
-                double lo = (double)0.001f, hi = (double)FLT_MAX;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const double t0 = fma(bl[a][k], cr.inv[a], -cr.oi[a]), t1 = fma(bh[a][k], cr.inv[a], -cr.oi[a]);
-                    lo = fmax(lo, fmin(t0, t1)), hi = fmin(hi, fmax(t0, t1));
-                }
-                meets[k] = lo <= hi && child[k] != -1;
-            }
-            int next = -1;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (!meets[k]) continue;
-                if (child[k] >= 0) {
-                    // descend into the last child that was hit; the others wait on the stack
-                    // (the host has checked that CAND_STACK entries are enough for this tree)
-                    if (next >= 0) lds.stack[sp++ * lds.stride] = (uint16_t)next;
-                    next = child[k];
-                    continue;
-                }
-                // mark the leaf: an LDS OR that returns nothing
+            const bool meets = work && lo <= hi && child[k] != -1;
+            if (meets && child[k] < 0) {
+                // a leaf: mark it in the bit column of the ray's lane (LDS ORs that return nothing)
                 const int leaf = -2 - child[k];
-                (void)__hip_atomic_fetch_or(bits + (leaf >> 5) * lds.stride, 1u << (leaf & 31), __ATOMIC_RELAXED,
+                (void)__hip_atomic_fetch_or(column + (leaf >> 5) * lds.stride, 1u << (leaf & 31), __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_WORKGROUP);
-                touched |= 1u << (leaf >> 5);
+                (void)__hip_atomic_fetch_or(column + CAND_WORDS * lds.stride, 1u << (leaf >> 5), __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if (next < 0) {
-                if (sp == 0) break;
-                next = lds.stack[--sp * lds.stride];
-            }
-            node = next;
+            // an inner node: the wave appends it to the queue
+            const bool push = meets && child[k] >= 0;
+            const unsigned long long pm = __ballot(push);
+            if (push)
+                queue[n_items + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u))] =
+                    (uint16_t)((owner << 10) | (uint32_t)child[k]);
+            n_items += (uint32_t)__popcll(pm);
         }
     }
-    REGION_END(st, ST_CAND_SEARCH, search);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    return complete;
+}
+// Candidate search for large trees (host side: build_candidate_tree). Phase 1 (wave_candidate_search) has
+// marked every leaf whose tight box the ray's line meets; this is phase 2, the reference's walk over the
+// marked leaves (ascending index = pre-order) with the walk's own node code. Gives the walk's result.
+// With `discard` the marks are only cleared.
+template <int FEAT>
+__device__ bool visit_candidates(SceneRef sv, const RayD& ray, D3 inv_d, const Rng& g, HitD& out, CandLds lds, bool discard,
+                                 Stamps& st) {
+    LDS_AS uint32_t* bits = lds.bits;
+    static_assert(CAND_WORDS <= 32, "one summary bit per word");
+    uint32_t touched = bits[CAND_WORDS * lds.stride];  // which words of the bit array hold marks
+    bits[CAND_WORDS * lds.stride] = 0;
+    if (discard) {
+        while (touched) {
+            bits[(__ffs((int)touched) - 1) * lds.stride] = 0;
+            touched &= touched - 1;
+        }
+        return false;
+    }
     STAMP_COUNT(st, 3);
+    STAMP_COUNT_WAVE(st, 6);
     LaneWalk w{(double)FLT_MAX, -1, 0, {0.0, 0.0, 0.0}, 0, 0};
     // The marked nodes are known before any of them is visited, so the next node's record is
     // requested while the current one is processed (the walk is bound by load latency).
@@ -1109,6 +1143,7 @@ __device__ bool nearest_hit_candidates(SceneRef sv, const RayD& ray, const Rng& 
         DLeafRec lr_next{};
         if (idx_next >= 0) nd_next = sv.nodes[idx_next], lr_next = sv.lane_leaf[idx_next];
         STAMP_COUNT(st, 2);
+        STAMP_COUNT_WAVE(st, 5);
         bool reach = true;
         if constexpr ((FEAT & FEAT_SPHERE) != 0) {
             if (nd.flags & NODE_DYNAMIC_BOX) {
@@ -1136,15 +1171,32 @@ __device__ bool nearest_hit_candidates(SceneRef sv, const RayD& ray, const Rng& 
     out.pos = w.best_pos;
     return w.best_obj >= 0;
 }
+// Per-lane nearest hit for large trees: the candidate search where the scene has its spatial tree, else (and
+// for the rays the search does not take) the plain walk. Every lane of the wave must call this; `live` marks
+// the lanes with a ray.
 template <int FEAT>
-__device__ bool nearest_hit_lane(SceneRef sv, const RayD& ray, const Rng& g, HitD& out, Stamps& st,
+__device__ bool nearest_hit_lane(SceneRef sv, const RayD& ray, const Rng& g, bool live, HitD& out, Stamps& st,
                                  CandLds lds = CandLds{nullptr, nullptr, 0}) {
-    // (a zero or non-finite direction component makes slab bounds undefined: those rays take the walk)
-    const double dmin = fmin(fabs(ray.d.x), fmin(fabs(ray.d.y), fabs(ray.d.z)));
-    const double dmax = fmax(fabs(ray.d.x), fmax(fabs(ray.d.y), fabs(ray.d.z)));
-    // (so do origins so far out that origin * inv loses the digits the boxes' safety margin covers)
-    const double omax = fmax(fabs(ray.o.x), fmax(fabs(ray.o.y), fabs(ray.o.z)));
-    if (sv.n_cand_nodes > 0 && lds.bits && dmin > 0.0 && dmax < INFINITY && omax < 1e6) return nearest_hit_candidates<FEAT>(sv, ray, g, out, lds, st);
+    // (`stride`, not a pointer, says whether the kernel has the search's LDS arrays: LDS address 0 is thread 0's
+    // column, and the test must come out the same for the whole wave)
+    if (sv.n_cand_nodes > 0 && lds.stride != 0) {
+        // (a zero or non-finite direction component makes slab bounds undefined: those rays take the walk)
+        const double dmin = fmin(fabs(ray.d.x), fmin(fabs(ray.d.y), fabs(ray.d.z)));
+        const double dmax = fmax(fabs(ray.d.x), fmax(fabs(ray.d.y), fabs(ray.d.z)));
+        // (so do origins so far out that origin * inv loses the digits the boxes' safety margin covers)
+        const double omax = fmax(fabs(ray.o.x), fmax(fabs(ray.o.y), fabs(ray.o.z)));
+        const bool search = live && dmin > 0.0 && dmax < INFINITY && omax < 1e6;
+        D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
+        const CandRay cr{{inv_d.x, inv_d.y, inv_d.z}, {ray.o.x * inv_d.x, ray.o.y * inv_d.y, ray.o.z * inv_d.z}, ray.time};
+        REGION_BEGIN(search_t);
+        const bool complete = wave_candidate_search(sv, cr, search, lds, st);
+        REGION_END(st, ST_CAND_SEARCH, search_t);
+        if (search) {
+            const bool hit = visit_candidates<FEAT>(sv, ray, inv_d, g, out, lds, !complete, st);
+            if (complete) return hit;
+        }
+    }
+    if (!live) return false;
     LaneWalk w{(double)FLT_MAX, -1, 0, {0.0, 0.0, 0.0}, 0, 0};
     D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
     int i = 0;
@@ -1970,7 +2022,7 @@ __device__ bool path_segment(SceneRef sv, RayD& ray, F3& thr, const Rng& g, bool
     if (WAVE) {
         hit = nearest_hit_wave<FEAT>(sv, ray, g, live, h, st);
     } else {
-        hit = live && nearest_hit_lane<FEAT>(sv, ray, g, h, st, cand_bits);
+        hit = nearest_hit_lane<FEAT>(sv, ray, g, live, h, st, cand_bits);
     }
     REGION_END(st, ST_TRAVERSE, trav);
     REGION_BEGIN(shade);
@@ -1990,12 +2042,14 @@ __device__ bool path_segment(SceneRef sv, RayD& ray, F3& thr, const Rng& g, bool
 }
 
 // ============================================================== kernels
-// This lane's columns of the workgroup's candidate-search arrays (nearest_hit_candidates), bits cleared.
+// This lane's bit column and this wave's queue of the workgroup's candidate-search arrays, bits cleared.
 __device__ __forceinline__ CandLds candidate_lds(SceneRef sv) {
     const uint32_t tpb = blockDim.x;
     uint32_t* base = dynamic_lds();
-    CandLds lds{(LDS_AS uint32_t*)base + threadIdx.x, (LDS_AS uint16_t*)(base + CAND_WORDS * tpb) + threadIdx.x, tpb};
+    CandLds lds{(LDS_AS uint32_t*)base + threadIdx.x,
+                (LDS_AS uint16_t*)(base + (CAND_WORDS + 1) * tpb) + (threadIdx.x >> 6) * CAND_QUEUE, tpb};
     for (int w = 0; w < sv.n_cand_words; ++w) lds.bits[w * tpb] = 0;
+    lds.bits[CAND_WORDS * tpb] = 0;
     return lds;
 }
 // Waves per SIMD the segment kernel is compiled for (512 / waves registers per lane), see seg_waves.
@@ -2009,7 +2063,7 @@ constexpr int seg_block(bool wave) { return wave ? 64 : 256; }
 // the candidate search).
 constexpr size_t lds_bytes(bool wave, int feat, int threads) {
     if (feat & FEAT_OCTREE) return sizeof(uint32_t) * OCT_ANC_LEVELS * (size_t)threads;
-    if (!wave) return (sizeof(uint32_t) * CAND_WORDS + sizeof(uint16_t) * CAND_STACK) * (size_t)threads;
+    if (!wave) return sizeof(uint32_t) * (CAND_WORDS + 1) * (size_t)threads + sizeof(uint16_t) * CAND_QUEUE * (size_t)(threads / 64);
     return 0;
 }
 #ifndef MRT_LANE_WAVES
@@ -2159,7 +2213,7 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
 #ifdef MRT_STAMPS
     for (int i = 0; i < ST_COUNT; ++i)
         if (st.acc[i]) atomicAdd(&ctr->stamps[i], st.acc[i]), atomicAdd(&ctr->stamp_lanes[i], st.lanes[i]);
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
         if (st.count[i]) atomicAdd(&ctr->stamp_counts[i], (unsigned long long)st.count[i]);
 #endif
     if (in_range) {
@@ -2246,7 +2300,7 @@ __global__ void __launch_bounds__(BLOCK) k_single_bounce(const SceneView* svp, R
     Rng g0(key, 0);
     CandLds cand_bits{nullptr, nullptr, 0};
     if constexpr (!WAVE && (FEAT & FEAT_OCTREE) == 0) cand_bits = candidate_lds(sv);
-    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g0, live, h, st) : (live && nearest_hit_lane<FEAT>(sv, ray, g0, h, st, cand_bits));
+    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g0, live, h, st) : nearest_hit_lane<FEAT>(sv, ray, g0, live, h, st, cand_bits);
     F3 color{0.f, 0.f, 0.f};
     if constexpr (MODE == MRT_SHADER_DIFFUSE) {
         if (live) color = diffuse_stage<FEAT>(sv, ray, h, hit);
@@ -2269,7 +2323,7 @@ __global__ void __launch_bounds__(BLOCK) k_single_bounce(const SceneView* svp, R
             if (hit) object_generate<LF>(lights + i, pos_w, h.t, gi, rng_f64(gi, MRT_DIM_LIGHT_A), rng_f64(gi, MRT_DIM_LIGHT_B), ai);
             HitD h2{0.0, -1, 0, {0.0, 0.0, 0.0}};
             bool hit2 = WAVE ? nearest_hit_wave<FEAT>(sv, ai.to_area, gi, hit, h2, st)
-                             : (hit && nearest_hit_lane<FEAT>(sv, ai.to_area, gi, h2, st, cand_bits));
+                             : nearest_hit_lane<FEAT>(sv, ai.to_area, gi, hit, h2, st, cand_bits);
             if (hit) rays++;
             if (hit && hit2) {
                 const DObjRec* ob2 = sv.objects + h2.obj;
@@ -2352,7 +2406,7 @@ __global__ void __launch_bounds__(BLOCK) k_trace_rays(const SceneView* svp, cons
     CandLds cand_bits{nullptr, nullptr, 0};
     // (kernels with octree code keep their LDS for the octree walk's ancestor cache)
     if constexpr (!WAVE && (FEAT & FEAT_OCTREE) == 0) cand_bits = candidate_lds(sv);
-    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g, live, h, st) : (live && nearest_hit_lane<FEAT>(sv, ray, g, h, st, cand_bits));
+    bool hit = WAVE ? nearest_hit_wave<FEAT>(sv, ray, g, live, h, st) : nearest_hit_lane<FEAT>(sv, ray, g, live, h, st, cand_bits);
     if (!live) return;
     D3 n_w{0, 0, 0}, p_w{0, 0, 0};
     if (hit) {
@@ -2842,6 +2896,10 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
                      (double)host.stamp_counts[0] / (double)std::max(1ull, host.stamp_counts[3]),
                      (double)host.stamp_counts[1] / (double)std::max(1ull, host.stamp_counts[3]),
                      (double)host.stamp_counts[2] / (double)std::max(1ull, host.stamp_counts[3]), host.stamp_counts[3]);
+        std::fprintf(stderr, "[stamps] per wave and query: %.1f rounds of the spatial search, %.1f rounds of leaf visits, %.1f lanes asking\n",
+                     (double)host.stamp_counts[4] / (double)std::max(1ull, host.stamp_counts[6]),
+                     (double)host.stamp_counts[5] / (double)std::max(1ull, host.stamp_counts[6]),
+                     (double)host.stamp_counts[3] / (double)std::max(1ull, host.stamp_counts[6]));
         std::fprintf(stderr, "[stamps] wave-cycles per region (share of total, active lanes of 64)\n");
         for (int i = 0; i < ST_COUNT; ++i)
             std::fprintf(stderr, "[stamps] %-22s %14llu  %5.1f%%  lanes %4.1f\n", names[i], host.stamps[i],

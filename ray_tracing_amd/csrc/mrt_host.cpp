@@ -483,7 +483,9 @@ void build_candidate_tree(FlatScene* s) {
     build_candidate_nodes(items, 0, items.size(), &b2);
     int need = 0;
     collapse(b2, 0, &s->cand_nodes, &need);
-    if (need > CAND_STACK || s->cand_nodes.size() > 65535) {
+    // (the device's queue entries hold the node index in ten bits; `need`, the depth of a lane's own stack, no
+    // longer limits anything: the wave's queue overflowing sends its rays to the plain walk)
+    if (s->cand_nodes.size() > 1024) {
         s->cand_nodes.clear();
         return;
     }
