@@ -114,7 +114,7 @@ struct Counters {
     unsigned long long held;  // work items claimed by waves but not started when the launch ended
     unsigned long long stamps[ST_COUNT];  // diagnostic build only
     unsigned long long stamp_lanes[ST_COUNT];
-    unsigned long long stamp_counts[8];
+    unsigned long long stamp_counts[12];
 };
 
 // Diagnostic build (-DMRT_STAMPS): wave-level cycle shares of the segment kernel's regions.
@@ -124,7 +124,7 @@ struct Counters {
 struct Stamps {
     unsigned long long acc[ST_COUNT];
     unsigned long long lanes[ST_COUNT];  // cycles x active lanes (lane utilisation of the region)
-    unsigned int count[8];               // event counts of the candidate search: 0-3 per lane, 4-6 per wave (rounds, queries)
+    unsigned int count[12];              // event counts: candidate search 0-3 per lane, 4-6 per wave (rounds, queries); octree walk 7 steps per lane, 8 step rounds per wave, 9 walks per wave, 10 walks per lane
 };
 #define STAMP_COUNT(st, i) ((st).count[i]++)
 #define STAMP_COUNT_WAVE(st, i) ((st).count[i] += (__lane_id() == (uint32_t)(__ffsll((long long)__ballot(1)) - 1)) ? 1u : 0u)
@@ -588,6 +588,10 @@ __device__ __forceinline__ int32_t floor_size(int32_t v, uint32_t s) { return (v
 //   6..11  solid hit by the edge effect of a volume voxel (its solid_material), normal code - 6
 //   12     volume hit: the free path ended inside the volume (material Volume { color }, normal +x)
 constexpr int OCT_SUB = 16;
+#ifdef MRT_STAMPS
+// diagnostic build: steps of the octree walk summed over lanes [0], step rounds summed over waves [1]
+__device__ unsigned long long g_oct_diag[2];
+#endif
 constexpr int OCT_EDGE = 6, OCT_VOLUME = 12;
 
 // RayTraceState::volume_distance_left (ray_trace.rs:93-104)
@@ -679,6 +683,13 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
     const D3 inv{rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z)};
     int32_t step = 1 << csz;  // get_step_size of the current block
     for (int it = 0; it < 3000; ++it) {
+#ifdef MRT_STAMPS
+        {
+            const unsigned long long act = __ballot(1);
+            if ((int)__lane_id() == __ffsll((long long)act) - 1)
+                atomicAdd(&g_oct_diag[0], (unsigned long long)__popcll(act)), atomicAdd(&g_oct_diag[1], 1ull);
+        }
+#endif
         // (the block is in range here: checked on entry, and every step below ends in a checked cell's block)
         double tx = ((double)(bx + (px ? step : 0)) - cur.x) * inv.x;
         double ty = ((double)(by + (py ? step : 0)) - cur.y) * inv.y;
@@ -2213,7 +2224,7 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
 #ifdef MRT_STAMPS
     for (int i = 0; i < ST_COUNT; ++i)
         if (st.acc[i]) atomicAdd(&ctr->stamps[i], st.acc[i]), atomicAdd(&ctr->stamp_lanes[i], st.lanes[i]);
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 12; ++i)
         if (st.count[i]) atomicAdd(&ctr->stamp_counts[i], (unsigned long long)st.count[i]);
 #endif
     if (in_range) {
@@ -2900,6 +2911,11 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
                      (double)host.stamp_counts[4] / (double)std::max(1ull, host.stamp_counts[6]),
                      (double)host.stamp_counts[5] / (double)std::max(1ull, host.stamp_counts[6]),
                      (double)host.stamp_counts[3] / (double)std::max(1ull, host.stamp_counts[6]));
+        {
+            unsigned long long od[2] = {0, 0};
+            (void)hipMemcpyFromSymbol(od, HIP_SYMBOL(g_oct_diag), sizeof(od));
+            if (od[1]) std::fprintf(stderr, "[stamps] octree walk: %llu lane steps in %llu wave rounds (all launches so far): %.1f of 64 lanes stepping\n", od[0], od[1], (double)od[0] / (double)od[1]);
+        }
         std::fprintf(stderr, "[stamps] wave-cycles per region (share of total, active lanes of 64)\n");
         for (int i = 0; i < ST_COUNT; ++i)
             std::fprintf(stderr, "[stamps] %-22s %14llu  %5.1f%%  lanes %4.1f\n", names[i], host.stamps[i],
