@@ -61,6 +61,9 @@ struct SceneView {
     DCamera cam;
     mrt_background bg;
     mrt_sun sun;
+    // constants of the scene that the reference works out per call with sin / cos (evaluated once, on the host):
+    double bg_sun_ray[3], bg_cos_sun_radius;  // SunSky::color, sun_sky.rs:32-60
+    double sun_dir[3], sun_cos_radius;        // Sun::make_direction_vector, sun.rs:17-20; SkyPdf::value, pdf.rs:135-148
 };
 #define CONST_AS __attribute__((address_space(4)))
 template <class T>
@@ -1676,11 +1679,6 @@ __device__ __forceinline__ Onb onb_from_w(D3 n) {
     D3 u = cross(w, v);
     return {u, v, w};
 }
-template <class S>
-__device__ __forceinline__ D3 sun_direction(const S& s) {  // sun.rs:17-20
-    double r = cos(s.phi);
-    return {r * cos(s.theta), sin(s.phi), r * sin(s.theta)};
-}
 
 // LambertianPDF::generate, pdf.rs:234-282, in two steps around the wave's unit-vector sampler: the choice of
 // the pdf with the draws every choice starts with (and whether it will need a vector in the unit ball), then
@@ -1759,7 +1757,7 @@ __device__ bool lambertian_generate(SceneRef sv, D3 pdf_normal, double incoming_
             double rr = sqrt(ua);                              // rand_scalar(0, 1)
             double theta = ub * (2.0 * M_PI - 0.0) + 0.0;      // rand_scalar(0, 2 pi)
             rr = rr * sv.sun.radius;
-            D3 svv = sun_direction(sv.sun);
+            D3 svv = ld3(sv.sun_dir);
             D3 k = normalize(cross(svv, D3{0.0, 0.0, 1.0}));
             dir = cos(rr) * svv + cross(k, svv) * sin(theta) + k * dot(k, svv) * (1.0 - cos(theta));
             double area = M_PI * (sv.sun.radius * sv.sun.radius);
@@ -1785,7 +1783,7 @@ __device__ bool lambertian_generate(SceneRef sv, D3 pdf_normal, double incoming_
     if (r != 2) {  // sky_pdf.value, pdf.rs:135-148
         double svl = 1.0;
         if constexpr ((FEAT & FEAT_SKY) != 0) {
-            if (sv.sun.has_sun) svl = dot(dir, sun_direction(sv.sun)) >= cos(sv.sun.radius) ? 1.0 : 0.0;
+            if (sv.sun.has_sun) svl = dot(dir, ld3(sv.sun_dir)) >= sv.sun_cos_radius ? 1.0 : 0.0;
         }
         sum += svl;
         total++;
@@ -1809,10 +1807,9 @@ __device__ F3 background_color(SceneRef sv, const RayD& ray) {
     const auto& b = sv.bg;
     if ((FEAT & FEAT_SKY) == 0 || b.kind == MRT_BG_CONSTANT) return {b.color[0], b.color[1], b.color[2]};  // constant_color.rs:12-14
     if (b.kind == MRT_BG_SUN_SKY) {  // sun_sky.rs:32-60
-        double r = cos(b.sun_phi);
-        D3 sun_ray{r * cos(b.sun_theta), sin(b.sun_phi), r * sin(b.sun_theta)};
-        double sun_cos = dot(sun_ray, normalize(ray.d));
-        if (sun_cos > cos(b.sun_radius) && sun_cos > 0.0) {
+        // (sun_ray = (cos phi cos theta, sin phi, cos phi sin theta) and cos(radius) come from the host)
+        double sun_cos = dot(ld3(sv.bg_sun_ray), normalize(ray.d));
+        if (sun_cos > sv.bg_cos_sun_radius && sun_cos > 0.0) {
             float k = (float)b.sun_brightness;
             return {k, k, k};
         }
@@ -2641,6 +2638,14 @@ int upload_scene(mrt_scene* sc) {
     v.cam = f.camera;
     v.bg = f.background;
     v.sun = f.sun;
+    {
+        const double r = std::cos(v.bg.sun_phi);
+        v.bg_sun_ray[0] = r * std::cos(v.bg.sun_theta), v.bg_sun_ray[1] = std::sin(v.bg.sun_phi), v.bg_sun_ray[2] = r * std::sin(v.bg.sun_theta);
+        v.bg_cos_sun_radius = std::cos(v.bg.sun_radius);
+        const double rs = std::cos(v.sun.phi);
+        v.sun_dir[0] = rs * std::cos(v.sun.theta), v.sun_dir[1] = std::sin(v.sun.phi), v.sun_dir[2] = rs * std::sin(v.sun.theta);
+        v.sun_cos_radius = std::cos(v.sun.radius);
+    }
     v.trace_zero_throughput = 0;
     if ((rc = m.alloc(sizeof(SceneView) * 2 * TRAV_CANDIDATES, reinterpret_cast<void**>(&sc->dev_views))) != MRT_OK) return rc;
     for (int mode = TRAV_LANE; mode <= TRAV_CANDIDATES; ++mode) {
