@@ -48,6 +48,7 @@ struct SceneView {
     int32_t trace_zero_throughput;
     int32_t n_cand_nodes;  // > 0: the per-lane query runs the candidate search instead of the walk
     int32_t n_cand_words;  // 32-node words of the candidate bit array in use
+    int32_t n_perlins;
     const DCand4* cand_nodes;
     const DObjRec* objects;  // one record per object (shape, transform, material)
     const DObjRec* lights;   // the light list, same record type
@@ -66,6 +67,7 @@ struct SceneView {
     double sun_dir[3], sun_cos_radius;        // Sun::make_direction_vector, sun.rs:17-20; SkyPdf::value, pdf.rs:135-148
 };
 #define CONST_AS __attribute__((address_space(4)))
+#define LDS_AS __attribute__((address_space(3)))
 template <class T>
 __device__ __forceinline__ const CONST_AS T* as_const(const T* p) {
     return (const CONST_AS T*)p;
@@ -982,7 +984,6 @@ struct CandRay {
     double inv[3], oi[3];
     double tau;  // the ray's time
 };
-#define LDS_AS __attribute__((address_space(3)))
 // LDS state of the candidate search. Per lane (columns of [row][threads per workgroup] arrays): a bit per
 // tree node, all zero between queries, in rows 0 .. CAND_WORDS - 1, and in row CAND_WORDS one bit per row
 // that holds marks. Per wave: the work queue of the spatial search, CAND_QUEUE entries.
@@ -1403,7 +1404,8 @@ __device__ __forceinline__ D3 point_to_world(OP ob, D3 p) {
 
 // ============================================================== textures (texture.rs)
 // Perlin::noise / trilinear_interp / turbulence, texture.rs:95-160
-__device__ __noinline__ double perlin_noise(const mrt_perlin& pn, D3 point) {
+template <class PN>
+__device__ __noinline__ double perlin_noise(PN pn, D3 point) {
     double fx = floor(point.x), fy = floor(point.y), fz = floor(point.z);
     double u = point.x - fx, v = point.y - fy, w = point.z - fz;
     int i = f64_as_i32(fx), j = f64_as_i32(fy), k = f64_as_i32(fz);
@@ -1412,15 +1414,16 @@ __device__ __noinline__ double perlin_noise(const mrt_perlin& pn, D3 point) {
     for (int di = 0; di < 2; ++di)
         for (int dj = 0; dj < 2; ++dj)
             for (int dk = 0; dk < 2; ++dk) {
-                uint32_t idx = pn.perm_x[(i + di) & 255] ^ pn.perm_y[(j + dj) & 255] ^ pn.perm_z[(k + dk) & 255];
-                const double* c = pn.ran_float[idx];
+                uint32_t idx = pn->perm_x[(i + di) & 255] ^ pn->perm_y[(j + dj) & 255] ^ pn->perm_z[(k + dk) & 255];
+                const auto c = pn->ran_float[idx];
                 double d = (c[0] * (u - (double)di) + c[1] * (v - (double)dj)) + c[2] * (w - (double)dk);  // cgmath dot
                 accum += (((double)di * uu + (double)(1 - di) * (1.0 - uu)) * ((double)dj * vv + (double)(1 - dj) * (1.0 - vv))) *
                          ((double)dk * ww + (double)(1 - dk) * (1.0 - ww)) * d;
             }
     return accum;
 }
-__device__ double perlin_turbulence(const mrt_perlin& pn, D3 point, int depth) {
+template <class PN>
+__device__ double perlin_turbulence(PN pn, D3 point, int depth) {
     double acum = 0.0, weight = 1.0;
     D3 tp = point;
 #pragma nounroll
@@ -1432,13 +1435,21 @@ __device__ double perlin_turbulence(const mrt_perlin& pn, D3 point, int depth) {
     return fabs(acum);
 }
 
+// The scene's first Perlin table staged in LDS by the kernels that have room for it (9 KB): a turbulence
+// value is seven noise evaluations of 14 dependent table lookups each, and from LDS a lookup returns in a
+// fraction of the time of a cache hit. `have` (not the pointer: LDS address 0 is a valid address) says
+// whether the copy exists.
+struct PerlinLds {
+    const LDS_AS mrt_perlin* table;
+    bool have;
+};
 __device__ __forceinline__ uint32_t f64_as_index(double v, uint32_t hi) {  // Rust `as usize` then clamp
     if (!(v > 0.0)) return 0;
     if (v >= (double)hi) return hi;
     return (uint32_t)v;
 }
 template <int FEAT>
-__device__ F3 texture_color(SceneRef sv, const DObjRec* sh, const Surface& sf) {
+__device__ F3 texture_color(SceneRef sv, const DObjRec* sh, const Surface& sf, PerlinLds pl = PerlinLds{nullptr, false}) {
     // SolidColor textures are folded into the object record
     if ((FEAT & FEAT_TEXTURE) == 0 || sh->tex_solid) return {sh->color[0], sh->color[1], sh->color[2]};
     const int tex = sh->texture;
@@ -1471,7 +1482,8 @@ __device__ F3 texture_color(SceneRef sv, const DObjRec* sh, const Surface& sf) {
                 break;
             case MRT_TEX_PERLIN: {  // texture.rs:185-189
                 if constexpr ((FEAT & FEAT_PERLIN) != 0) {
-                    float f = (float)perlin_turbulence(sv.perlins[t.image], 2.0 * pos, 7);
+                    float f = pl.have && t.image == 0 ? (float)perlin_turbulence(pl.table, 2.0 * pos, 7)
+                                                      : (float)perlin_turbulence(sv.perlins + t.image, 2.0 * pos, 7);
                     c = {f, f, f};
                 }
                 break;
@@ -1888,7 +1900,7 @@ struct ShadeCtx {
 };
 template <int FEAT>
 __device__ bool shade_prepare(SceneRef sv, const RayD& ray, const F3& thr, const Rng& g, const HitD& h, bool hit,
-                              F3& radiance, ShadeCtx& c, bool& want_vec, uint32_t& vec_dim, Stamps& st) {
+                              F3& radiance, ShadeCtx& c, bool& want_vec, uint32_t& vec_dim, Stamps& st, PerlinLds pl) {
     radiance = {0.f, 0.f, 0.f};
     if (!hit) {
         F3 bg = background_color<FEAT>(sv, ray);
@@ -1908,7 +1920,7 @@ __device__ bool shade_prepare(SceneRef sv, const RayD& ray, const F3& thr, const
     if (voxel_mat) {
         if constexpr ((FEAT & FEAT_OCTREE) != 0) mkind = voxel_material<FEAT>(sv, s, att, fuzz);
     } else if (mkind != MRT_MAT_DIELECTRIC) {
-        att = texture_color<FEAT>(sv, ob, s);
+        att = texture_color<FEAT>(sv, ob, s, pl);
     }
     c.mkind = mkind, c.fuzz = fuzz, c.att = att;
     REGION_END(st, ST_SURFACE, surf);
@@ -2022,7 +2034,7 @@ __device__ bool shade_finish(SceneRef sv, RayD& ray, F3& thr, const Rng& g, doub
 // sampler are wave-wide).
 template <bool WAVE, int FEAT>
 __device__ bool path_segment(SceneRef sv, RayD& ray, F3& thr, const Rng& g, bool live, F3& radiance,
-                             uint32_t& rays, uint32_t& light_queries, Stamps& st, CandLds cand_bits) {
+                             uint32_t& rays, uint32_t& light_queries, Stamps& st, CandLds cand_bits, PerlinLds pl) {
     radiance = {0.f, 0.f, 0.f};
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     bool hit;
@@ -2039,7 +2051,7 @@ __device__ bool path_segment(SceneRef sv, RayD& ray, F3& thr, const Rng& g, bool
     uint32_t vec_dim = 0;
     if (live) {
         rays++;
-        more = shade_prepare<FEAT>(sv, ray, thr, g, h, hit, radiance, c, want_vec, vec_dim, st);
+        more = shade_prepare<FEAT>(sv, ray, thr, g, h, hit, radiance, c, want_vec, vec_dim, st, pl);
     }
     REGION_BEGIN(uvec);
     const D3 unit_vec = wave_rand_unit_vec(want_vec, g.base, vec_dim);
@@ -2139,6 +2151,19 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
     CandLds cand_bits{nullptr, nullptr, 0};
     // (kernels with octree code keep their LDS for the octree walk's ancestor cache)
     if constexpr (!WAVE && (FEAT & FEAT_OCTREE) == 0) cand_bits = candidate_lds(sv);
+    PerlinLds perlin_lds{nullptr, false};
+    if constexpr (WAVE && (FEAT & FEAT_PERLIN) != 0 && (FEAT & FEAT_OCTREE) == 0) {
+        // (single-wave workgroups: the wave copies the table for itself, no barrier)
+        __shared__ mrt_perlin perlin_table;
+        static_assert(sizeof(mrt_perlin) % (4 * 64) == 0, "copied as whole rows of 64 dwords");
+        if (sv.n_perlins > 0) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(sv.perlins);
+            LDS_AS uint32_t* dst = (LDS_AS uint32_t*)reinterpret_cast<uint32_t*>(&perlin_table);
+            for (uint32_t i = threadIdx.x; i < sizeof(mrt_perlin) / 4; i += seg_block(WAVE)) dst[i] = src[i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            perlin_lds = {(const LDS_AS mrt_perlin*)&perlin_table, true};
+        }
+    }
     Stamps st{};
     REGION_BEGIN(total);
     for (uint32_t step = 0; step < rp.steps; ++step) {
@@ -2200,7 +2225,7 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
         if (WAVE && !__any(live)) break;
         Rng g{key, (uint32_t)(live ? seg : 0)};
         F3 radiance;
-        bool cont = path_segment<WAVE, FEAT>(sv, ray, thr, g, live, radiance, rays, light_queries, st, cand_bits);
+        bool cont = path_segment<WAVE, FEAT>(sv, ray, thr, g, live, radiance, rays, light_queries, st, cand_bits, perlin_lds);
         REGION_BEGIN(acc);
         if (live) {
             seg++;
@@ -2635,6 +2660,7 @@ int upload_scene(mrt_scene* sc) {
     v.n_cand_words = f.cand_nodes.empty() ? 0 : (int32_t)((f.node_object.size() + 31) / 32);
     v.n_objects = (int32_t)f.objects.size();
     v.n_lights = (int32_t)f.lights.size();
+    v.n_perlins = (int32_t)f.perlins.size();
     v.cam = f.camera;
     v.bg = f.background;
     v.sun = f.sun;
