@@ -375,8 +375,8 @@ int mrt_render_accumulate_device(mrt_scene* scene, float* accum_rgb_device, uint
  * contents (each call resets what it reads): calls on one GPU, from any thread and for any scene,
  * take turns on a per-GPU lock inside the library; a second PROCESS's calls are not ordered
  * against it but have their own copy of the array. */
-#define MRT_NOALLOC_POOL_SLOTS 262144u
-#define MRT_NOALLOC_SCRATCH_BYTES 22086144u
+#define MRT_NOALLOC_POOL_SLOTS 524288u
+#define MRT_NOALLOC_SCRATCH_BYTES 44171776u
 int mrt_render_accumulate_device_noalloc(mrt_scene* scene, float* accum_rgb_device, uint32_t width,
                                          uint32_t height, uint32_t x0, uint32_t strip_w, uint32_t spp,
                                          uint64_t seed, uint64_t first_sample_index, void* stream,

@@ -2462,12 +2462,13 @@ __global__ void __launch_bounds__(BLOCK) k_trace_rays(const SceneView* svp, cons
 using namespace mrt;
 
 // ---- device memory of mrt_render_accumulate_device_noalloc, the render entry point that allocates
-// nothing: one path pool of NOALLOC_SLOTS slots (4096 waves = four waves per SIMD of a 256-CU GPU,
-// i.e. one generation of resident waves), the counters and the per-wave work ranges, in a
-// file-scope device array that every GPU the library runs on holds until the process ends.
+// nothing: one path pool of NOALLOC_SLOTS slots (8192 waves = two generations of the waves a 256-CU
+// GPU holds at four per SIMD; with exactly one generation about an eighth of the wave slots stays
+// empty, measured), the counters and the per-wave work ranges, in a file-scope device array that
+// every GPU the library runs on holds until the process ends.
 // In host code the array's name is only a handle for hipGetSymbolAddress; the address the kernels
 // get is the per-device pointer resolved by resolve_scratch().
-constexpr uint32_t NOALLOC_SLOTS = 4096u * 64u;
+constexpr uint32_t NOALLOC_SLOTS = 8192u * 64u;
 constexpr size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
 struct ScratchLayout {
     size_t pool, counters, wave_chunks, total;

@@ -30,7 +30,7 @@ def test_noalloc_matches_allocating_entry_point_twice(name):
     from tests.helpers import scene_by_name
     lib = F.load()
     rt = RayTracer(scene_by_name(name), device=0, seed=5)
-    # first call: more paths than the scratch pool has slots (262,144), so every slot is used and regenerated
+    # first call: more paths than the scratch pool has slots (524,288), so every slot is used and regenerated
     calls = [(640, 360, 3, 2, 0, None), (97, 61, 2, 7, 5, 40)]
     for w, h, spp, first, x0, sw in calls:
         buf = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
