@@ -2086,6 +2086,8 @@ constexpr size_t lds_bytes(bool wave, int feat, int threads) {
     if (!wave) return sizeof(uint32_t) * (CAND_WORDS + 1) * (size_t)threads + sizeof(uint16_t) * CAND_QUEUE * (size_t)(threads / 64);
     return 0;
 }
+// Waves per SIMD per kernel class; the macros exist so that a library can be built per setting and the
+// settings compared on the same scenes (scripts/perf_variants.sh).
 #ifndef MRT_LANE_WAVES
 #define MRT_LANE_WAVES 3
 #endif
@@ -2099,6 +2101,8 @@ constexpr size_t lds_bytes(bool wave, int feat, int threads) {
 #define MRT_OCTREE_WAVES 3
 #endif
 constexpr int seg_waves(bool wave, int feat) {
+    // the per-lane kernels: two waves measured 9 % slower, a cap of 128 registers 31 % slower (spills), and their
+    // LDS arrays allow three workgroups per CU
     if (!wave) return MRT_LANE_WAVES;
     // measured per feature set (with the loop's constants and arguments no longer hoisted into registers, and the
     // scene view read through a pointer): the wave-synchronous kernels without octree code gain from a fourth wave
