@@ -434,6 +434,10 @@ enum mrt_shader { MRT_SHADER_RAYTRACING = 0, MRT_SHADER_DIFFUSE = 1, MRT_SHADER_
  *                            leaves and their ancestors only; auto picks it for
  *                            trees of more than 64 nodes; scenes with media, octrees
  *                            or more than 1024 tree nodes fall back to 1)
+ *   "candidate_queue"        entries of the per-wave work queue of the candidate
+ *                            search, 256..2048 (default 2048). A wave whose queue
+ *                            could overflow takes the tree walk for its rays (same
+ *                            result); smaller values exist to test that path.
  *   "trace_zero_throughput"  1: keep walking paths whose throughput is exactly
  *                            zero, as the reference does (same image, counters
  *                            match the reference's)

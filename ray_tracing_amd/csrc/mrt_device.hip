@@ -49,6 +49,7 @@ struct SceneView {
     int32_t n_cand_nodes;  // > 0: the per-lane query runs the candidate search instead of the walk
     int32_t n_cand_words;  // 32-node words of the candidate bit array in use
     int32_t n_perlins;
+    int32_t cand_queue;    // entries of a wave's search queue in use (CAND_QUEUE; smaller only to test the overflow path)
     const DCand4* cand_nodes;
     const DObjRec* objects;  // one record per object (shape, transform, material)
     const DObjRec* lights;   // the light list, same record type
@@ -1014,7 +1015,7 @@ __device__ bool wave_candidate_search(SceneRef sv, const CandRay& cr, bool askin
     while (n_items > 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const uint32_t take = n_items < 64u ? n_items : 64u;
-        if (n_items + 3u * take > (uint32_t)CAND_QUEUE) {
+        if (n_items + 3u * take > (uint32_t)sv.cand_queue) {
             complete = false;
             break;
         }
@@ -2645,6 +2646,18 @@ static SceneView view_for(const mrt_scene* sc, int mode) {
 
 namespace {
 
+// Writes the device copies of the scene view (the scene's device is current).
+int upload_views(mrt_scene* sc) {
+    for (int mode = TRAV_LANE; mode <= TRAV_CANDIDATES; ++mode) {
+        for (int tz = 0; tz < 2; ++tz) {
+            SceneView dv = view_for(sc, mode);
+            dv.trace_zero_throughput = tz;
+            HIP_TRY(hipMemcpy(sc->dev_views + (mode - 1) * 2 + tz, &dv, sizeof(SceneView), hipMemcpyHostToDevice));
+        }
+    }
+    return MRT_OK;
+}
+
 int upload_scene(mrt_scene* sc) {
     FlatScene& f = sc->flat;
     SceneView& v = sc->view;
@@ -2678,15 +2691,9 @@ int upload_scene(mrt_scene* sc) {
         v.sun_cos_radius = std::cos(v.sun.radius);
     }
     v.trace_zero_throughput = 0;
+    v.cand_queue = CAND_QUEUE;
     if ((rc = m.alloc(sizeof(SceneView) * 2 * TRAV_CANDIDATES, reinterpret_cast<void**>(&sc->dev_views))) != MRT_OK) return rc;
-    for (int mode = TRAV_LANE; mode <= TRAV_CANDIDATES; ++mode) {
-        for (int tz = 0; tz < 2; ++tz) {
-            SceneView dv = view_for(sc, mode);
-            dv.trace_zero_throughput = tz;
-            HIP_TRY(hipMemcpy(sc->dev_views + (mode - 1) * 2 + tz, &dv, sizeof(SceneView), hipMemcpyHostToDevice));
-        }
-    }
-    return MRT_OK;
+    return upload_views(sc);
 }
 // The device copy of view_for(sc, mode) with "trace_zero_throughput" set as given.
 const SceneView* device_view(const mrt_scene* sc, int mode, bool trace_zero) {
@@ -3253,6 +3260,12 @@ int mrt_scene_set_option(mrt_scene* scene, const char* name, int64_t value) {
     } else if (n == "traversal") {
         if (value < 0 || value > 4) return set_error(MRT_ERR_INVALID_ARGUMENT, "traversal must be 0..4");
         scene->opt_traversal = value;
+    } else if (n == "candidate_queue") {
+        if (value < 256 || value > CAND_QUEUE) return set_error(MRT_ERR_INVALID_ARGUMENT, "candidate_queue must be 256..2048");
+        if (scene->device < 0) return set_error(MRT_ERR_INVALID_ARGUMENT, "scene has no device image");
+        HIP_TRY(hipSetDevice(scene->device));
+        scene->view.cand_queue = (int32_t)value;
+        return upload_views(scene);
     } else {
         return set_error(MRT_ERR_INVALID_ARGUMENT, "unknown option: " + n);
     }

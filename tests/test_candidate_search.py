@@ -107,3 +107,22 @@ def test_scenes_that_do_not_qualify_fall_back():
     b, sb = gpu_render(rt, 64, 64, 4)
     assert sa.rays == sb.rays
     np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_a_full_search_queue_falls_back_to_the_walk():
+    """With the smallest work queue most waves of a crowded scene cannot finish the spatial search; their rays
+    take the tree walk instead, and nothing changes in the result."""
+    rt = RayTracer(crowded_scene(5, 700), device=0, seed=5)
+    rays = path_like_rays(rt, 320, 180, 40000, 5)
+    rt.world.set_option("traversal", 1)
+    o1, t1, n1, p1, f1 = rt.world.trace_rays(rays, seed=5)
+    rt.world.set_option("traversal", 4)
+    rt.world.set_option("candidate_queue", 256)
+    o4, t4, n4, p4, f4 = rt.world.trace_rays(rays, seed=5)
+    assert (o1 == o4).all() and (t1 == t4).all() and (n1 == n4).all() and (f1 == f4).all()
+    a, sa = gpu_render(rt, 160, 90, 4)
+    rt.world.set_option("candidate_queue", 2048)
+    b, sb = gpu_render(rt, 160, 90, 4)       # the queue at full size again: the marks of the earlier calls are gone
+    o5, t5, *_ = rt.world.trace_rays(rays, seed=5)
+    assert sa.rays == sb.rays and (o5 == o1).all() and (t5 == t1).all()
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
