@@ -191,7 +191,8 @@ enum : int {
     FEAT_SKY = 32,      // Sky / SunSky background, or a sun in the sky pdf
     FEAT_PERLIN = 64,   // Perlin textures (implies FEAT_TEXTURE)
     FEAT_VOLUME = 128,  // volume / reflecting voxels in an octree (implies FEAT_OCTREE)
-    FEAT_ALL = 255
+    FEAT_MOVING = 256,  // MovingSphere shapes (implies FEAT_SPHERE): centre by ray time, leaf boxes that depend on the query
+    FEAT_ALL = 511
 };
 
 // ============================================================== small vector math
@@ -494,7 +495,7 @@ __device__ __forceinline__ bool solid_hit_kp(int kind, PP p, const RayD& r, D3 i
             if constexpr ((FEAT & FEAT_SPHERE) != 0) return sphere_hit(D3{p[1], p[2], p[3]}, p[0], r, t_min, t_max, t);
             return false;
         case MRT_SHAPE_MOVING_SPHERE:
-            if constexpr ((FEAT & FEAT_SPHERE) != 0) return sphere_hit(moving_center(p, r.time), p[0], r, t_min, t_max, t);
+            if constexpr ((FEAT & FEAT_MOVING) != 0) return sphere_hit(moving_center(p, r.time), p[0], r, t_min, t_max, t);
             return false;
         case MRT_SHAPE_XY_RECT: return rect_hit<2>(p[0], p[1], p[2], p[3], p[4], r, inv, t_min, t_max, t);
         case MRT_SHAPE_XZ_RECT: return rect_hit<1>(p[0], p[1], p[2], p[3], p[4], r, inv, t_min, t_max, t);
@@ -505,27 +506,21 @@ __device__ __forceinline__ bool solid_hit_kp(int kind, PP p, const RayD& r, D3 i
 }
 
 // Aabb::hit (bvh.rs:18-33): every axis is tested on its own against the ORIGINAL [t_min, t_max].
+// Straight-line: the three axes are independent, and a wave gains nothing from leaving after the first
+// (some lane nearly always goes on), while every exit is a branch around a handful of instructions.
 __device__ __forceinline__ bool aabb_hit(D3 mn, D3 mx, const RayD& r, D3 inv_d, double t_min, double t_max) {
 #pragma clang fp contract(off)
-    {
-        double t0 = (mn.x - r.o.x) * inv_d.x, t1 = (mx.x - r.o.x) * inv_d.x;
-        if (inv_d.x < 0.0) { double s = t0; t0 = t1; t1 = s; }
-        double lo = fmax(t0, t_min), hi = fmin(t1, t_max);  // a NaN slab bound (0 * inf) leaves t_min / t_max
-        if (hi < lo) return false;
-    }
-    {
-        double t0 = (mn.y - r.o.y) * inv_d.y, t1 = (mx.y - r.o.y) * inv_d.y;
-        if (inv_d.y < 0.0) { double s = t0; t0 = t1; t1 = s; }
-        double lo = fmax(t0, t_min), hi = fmin(t1, t_max);  // a NaN slab bound (0 * inf) leaves t_min / t_max
-        if (hi < lo) return false;
-    }
-    {
-        double t0 = (mn.z - r.o.z) * inv_d.z, t1 = (mx.z - r.o.z) * inv_d.z;
-        if (inv_d.z < 0.0) { double s = t0; t0 = t1; t1 = s; }
-        double lo = fmax(t0, t_min), hi = fmin(t1, t_max);  // a NaN slab bound (0 * inf) leaves t_min / t_max
-        if (hi < lo) return false;
-    }
-    return true;
+    double x0 = (mn.x - r.o.x) * inv_d.x, x1 = (mx.x - r.o.x) * inv_d.x;
+    double y0 = (mn.y - r.o.y) * inv_d.y, y1 = (mx.y - r.o.y) * inv_d.y;
+    double z0 = (mn.z - r.o.z) * inv_d.z, z1 = (mx.z - r.o.z) * inv_d.z;
+    if (inv_d.x < 0.0) { double s = x0; x0 = x1; x1 = s; }
+    if (inv_d.y < 0.0) { double s = y0; y0 = y1; y1 = s; }
+    if (inv_d.z < 0.0) { double s = z0; z0 = z1; z1 = s; }
+    // a NaN slab bound (0 * inf) leaves t_min / t_max
+    const bool fx = fmin(x1, t_max) < fmax(x0, t_min);
+    const bool fy = fmin(y1, t_max) < fmax(y0, t_min);
+    const bool fz = fmin(z1, t_max) < fmax(z0, t_min);
+    return !(fx | fy | fz);
 }
 
 // ============================================================== voxel octree (fast_oct_tree/)
@@ -958,14 +953,15 @@ __device__ __forceinline__ bool lane_visit(SceneRef sv, const DNode& nd, const D
     const int4 head{lr.kind, lr.gkind, lr.identity, lr.octree};
     const double* p = lr.p;
     const bool identity = head.z == 1, translation = head.z == 2;
-    if constexpr ((FEAT & FEAT_SPHERE) != 0) {
+    if constexpr ((FEAT & FEAT_MOVING) != 0) {
         if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(ob, p, identity, t_min, w.closest, mn, mx);
     }
     if (!aabb_hit(mn, mx, ray, inv_d, t_min, w.closest)) return false;
     if (obj >= 0) {
         bool is_medium = false;
         if constexpr ((FEAT & FEAT_MEDIUM) != 0) is_medium = head.x == MRT_SHAPE_CONSTANT_MEDIUM;
-        const int rounds = (flags & NODE_TWICE) ? 2 : 1;
+        // (only stochastic shapes -- media, octrees with volume voxels -- are ever marked)
+        const int rounds = ((FEAT & (FEAT_MEDIUM | FEAT_VOLUME)) != 0 && (flags & NODE_TWICE)) ? 2 : 1;
 #pragma nounroll
         for (int round = 0; round < rounds; ++round) {
             if (round == 1 && !aabb_hit(mn, mx, ray, inv_d, t_min, w.closest)) break;
@@ -1161,7 +1157,7 @@ __device__ bool visit_candidates(SceneRef sv, const RayD& ray, D3 inv_d, const R
         STAMP_COUNT(st, 2);
         STAMP_COUNT_WAVE(st, 5);
         bool reach = true;
-        if constexpr ((FEAT & FEAT_SPHERE) != 0) {
+        if constexpr ((FEAT & FEAT_MOVING) != 0) {
             if (nd.flags & NODE_DYNAMIC_BOX) {
                 if (nd.parent != last_parent) {
                     last_parent = nd.parent;
@@ -1247,45 +1243,55 @@ __device__ bool nearest_hit_wave(SceneRef sv, const RayD& ray, const Rng& g, boo
     auto recs = as_const(sv.node_recs);
     int resume = live ? 0 : n;
     int i = 0;
+    // (wave-uniform) the node at hand is a NODE_TWICE node on its second evaluation. The second evaluation is one
+    // more turn of this loop on the same node -- box test against the updated bound by the lanes that passed the
+    // first, then the leaf -- so that the loop body holds one box test and one leaf test.
+    bool second = false;
     while (i < n) {
         auto r = recs + i;  // wave-uniform: every field below is a scalar load
         const int obj = r->object;
         const int flags = r->flags;
         const int skip = r->skip;
-        D3 mn{r->bmin[0], r->bmin[1], r->bmin[2]};
-        D3 mx{r->bmax[0], r->bmax[1], r->bmax[2]};
         bool pass = false;
         if (i >= resume) {
-            if constexpr ((FEAT & FEAT_SPHERE) != 0) {
-                if (flags & NODE_DYNAMIC_BOX)
-                    dynamic_leaf_box(as_const(sv.objects) + obj, r->p, r->identity != 0, t_min, closest, mn, mx);
+            bool dynamic = false;
+            if constexpr ((FEAT & FEAT_MOVING) != 0) dynamic = (flags & NODE_DYNAMIC_BOX) != 0;
+            if (dynamic) {
+                D3 mn, mx;
+                dynamic_leaf_box(as_const(sv.objects) + obj, r->p, r->identity != 0, t_min, closest, mn, mx);
+                pass = aabb_hit(mn, mx, ray, inv_d, t_min, closest);
+            } else {
+                pass = aabb_hit(D3{r->bmin[0], r->bmin[1], r->bmin[2]}, D3{r->bmax[0], r->bmax[1], r->bmax[2]}, ray, inv_d, t_min, closest);
             }
-            pass = aabb_hit(mn, mx, ray, inv_d, t_min, closest);
             if (!pass) resume = skip;
         }
         if (!__any(pass)) {
             i = skip;
+            second = false;
             continue;
         }
         if (obj >= 0) {
             REGION_BEGIN(leaf);
             bool is_medium = false;
             if constexpr ((FEAT & FEAT_MEDIUM) != 0) is_medium = r->kind == MRT_SHAPE_CONSTANT_MEDIUM;
-            const int rounds = (flags & NODE_TWICE) ? 2 : 1;
-#pragma nounroll
-            for (int round = 0; round < rounds; ++round) {
-                if (round == 1) pass = pass && aabb_hit(mn, mx, ray, inv_d, t_min, closest);
-                if (pass) {
-                    double t;
-                    int sub;
-                    if (node_hit<FEAT>(sv, r, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, oct_entry, t, sub, best_pos)) {
-                        closest = t, best_obj = obj, best_sub = sub;
-                    }
-                    if (is_medium) medium_ordinal++;
+            if (pass) {
+                double t;
+                int sub;
+                if (node_hit<FEAT>(sv, r, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, oct_entry, t, sub, best_pos)) {
+                    closest = t, best_obj = obj, best_sub = sub;
                 }
+                if (is_medium) medium_ordinal++;
             }
             REGION_END(st, is_medium ? ST_MEDIUM_TAIL : ST_LEAF, leaf);
+            // (only stochastic shapes -- media, octrees with volume voxels -- are ever marked)
+            if constexpr ((FEAT & (FEAT_MEDIUM | FEAT_VOLUME)) != 0) {
+                if ((flags & NODE_TWICE) != 0 && !second) {
+                    second = true;
+                    continue;
+                }
+            }
         }
+        second = false;
         i = i + 1;
     }
     out.t = closest;
@@ -1364,7 +1370,7 @@ __device__ void surface_at(OP ob, const RayD& ray, double t, int sub, D3 oct_pos
             if constexpr ((FEAT & FEAT_SPHERE) != 0) s.n_obj = (s.pos_obj - D3{p[1], p[2], p[3]}) * rcp_fast(p[0]);
             break;
         case MRT_SHAPE_MOVING_SPHERE:
-            if constexpr ((FEAT & FEAT_SPHERE) != 0) s.n_obj = (s.pos_obj - moving_center(p, sr.time)) * rcp_fast(p[0]);
+            if constexpr ((FEAT & FEAT_MOVING) != 0) s.n_obj = (s.pos_obj - moving_center(p, sr.time)) * rcp_fast(p[0]);
             break;
         case MRT_SHAPE_XY_RECT: s.n_obj = {0.0, 0.0, p[5]}; break;
         case MRT_SHAPE_XZ_RECT: s.n_obj = {0.0, p[5], 0.0}; break;
@@ -2584,7 +2590,7 @@ struct mrt_scene {
 template <int... M>
 struct FeatList {};
 constexpr int FEAT_NO_OCTREE = FEAT_ALL & ~(FEAT_OCTREE | FEAT_VOLUME);
-using KernelFeats = FeatList<0, FEAT_MEDIUM, FEAT_SPHERE | FEAT_MEDIUM, FEAT_SPHERE | FEAT_SPECULAR | FEAT_SKY,
+using KernelFeats = FeatList<0, FEAT_MEDIUM, FEAT_SPHERE | FEAT_MEDIUM, FEAT_SPHERE | FEAT_MOVING | FEAT_SPECULAR | FEAT_SKY,
                              FEAT_SPHERE | FEAT_SPECULAR | FEAT_TEXTURE | FEAT_SKY,
                              FEAT_NO_OCTREE, FEAT_OCTREE | FEAT_SKY, FEAT_OCTREE | FEAT_SPHERE | FEAT_SKY,
                              FEAT_OCTREE | FEAT_VOLUME | FEAT_SPHERE | FEAT_SKY, FEAT_ALL>;
@@ -2604,6 +2610,7 @@ static int scene_features(const FlatScene& f) {
     for (const DShape& sh : f.shapes) {
         if (sh.kind == MRT_SHAPE_OCTREE) need |= FEAT_OCTREE;
         if (sh.kind == MRT_SHAPE_SPHERE || sh.kind == MRT_SHAPE_MOVING_SPHERE) need |= FEAT_SPHERE;
+        if (sh.kind == MRT_SHAPE_MOVING_SPHERE) need |= FEAT_MOVING;
         if (sh.kind == MRT_SHAPE_CONSTANT_MEDIUM) need |= FEAT_MEDIUM;
     }
     for (const DMaterial& m : f.materials)
