@@ -24,6 +24,10 @@ stamps: ray_tracing_amd/libmrt_stamps.so
 ray_tracing_amd/libmrt_stamps.so: $(CSRC)/mrt_device.hip $(CSRC)/mrt_post.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_octree.cpp $(CSRC)/mrt_internal.h include/mrt.h
 	$(HIPCC) $(HIPFLAGS) -DMRT_STAMPS -shared -o $@ $(CSRC)/mrt_device.hip $(CSRC)/mrt_post.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_octree.cpp
 
+# Experiment builds: make variant TAG=name DEFS="-DMRT_..." -> ray_tracing_amd/libmrt_name.so (timed with scripts/perf_variants.sh)
+variant:
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -shared -o ray_tracing_amd/libmrt_$(TAG).so $(CSRC)/mrt_device.hip $(CSRC)/mrt_post.hip $(CSRC)/mrt_host.cpp $(CSRC)/mrt_octree.cpp
+
 oracle: $(ORACLE)
 
 # -march=native is deliberately NOT used: the .so is built here and run on the GPU box's host.
@@ -34,4 +38,4 @@ $(ORACLE): oracle/cpu_ref.cpp oracle/octree_api.cpp oracle/post_ref.cpp oracle/o
 clean:
 	rm -f $(LIB) $(ORACLE)
 
-.PHONY: all lib oracle stamps clean
+.PHONY: all lib oracle stamps variant clean
