@@ -1271,7 +1271,9 @@ __device__ bool nearest_hit_wave(SceneRef sv, const RayD& ray, const Rng& g, boo
         if (i >= resume) {
             bool dynamic = false;
             if constexpr ((FEAT & FEAT_MOVING) != 0) dynamic = (flags & NODE_DYNAMIC_BOX) != 0;
-            if (dynamic) {
+            if ((flags & NODE_BOX_IMPLIED) != 0) {
+                pass = true;  // the leaf's shape test decides (an untransformed rectangle)
+            } else if (dynamic) {
                 D3 mn, mx;
                 dynamic_leaf_box(as_const(sv.objects) + obj, r->p, r->identity != 0, t_min, closest, mn, mx);
                 pass = aabb_hit(mn, mx, ray, inv_d, t_min, closest);
