@@ -1686,21 +1686,25 @@ __device__ bool light_pdf_value(SceneRef sv, const RayD& ray, const Rng& g, uint
         }
     }
     if (!any) return false;
-    const DObjRec* ob = sv.lights + best;
-    Surface s;
-    surface_at<LF>(ob, ray, best_t, best_sub, D3{0.0, 0.0, 0.0}, s);
-    D3 hit_pos = point_to_world(ob, s.pos_obj);
-    D3 hit_n = normal_to_world(ob, s.n_obj);
-    D3 to_light = hit_pos - ray.o;
-    double light_cos = fabs(dot(normalize(to_light), hit_n));
-    if (light_cos >= 0.000001) {
-        // Object::prob applies the INVERSE transform to the ray (hittable.rs:284-287)
-        RayD pr{ray.o, normalize(to_light), best_t};
-        RayD tr = xform_ray(&ob->to_world, ob->identity != 0, pr);
-        value = shape_prob<LF>(ob, tr);
-    } else {
-        value = 0.0;
-    }
+    // (a one-entry list: the light's record is the same for every lane and is read with scalar loads)
+    auto value_at = [&](auto ob) {
+        Surface s;
+        surface_at<LF>(ob, ray, best_t, best_sub, D3{0.0, 0.0, 0.0}, s);
+        D3 hit_pos = point_to_world(ob, s.pos_obj);
+        D3 hit_n = normal_to_world(ob, s.n_obj);
+        D3 to_light = hit_pos - ray.o;
+        double light_cos = fabs(dot(normalize(to_light), hit_n));
+        if (light_cos >= 0.000001) {
+            // Object::prob applies the INVERSE transform to the ray (hittable.rs:284-287)
+            RayD pr{ray.o, normalize(to_light), best_t};
+            RayD tr = xform_ray(&ob->to_world, ob->identity != 0, pr);
+            value = shape_prob<LF>(ob, tr);
+        } else {
+            value = 0.0;
+        }
+    };
+    if (sv.n_lights == 1) value_at(as_const(sv.lights));
+    else value_at(sv.lights + best);
     return true;
 }
 
@@ -1744,7 +1748,8 @@ __device__ __forceinline__ void lambertian_choose(SceneRef sv, const Rng& g, Lam
         // a one-entry list needs no draw (x % 1 == 0; draws are addressed by dimension)
         if (sv.n_lights > 1) c.light = rand_u32(g, 0, (uint32_t)sv.n_lights, MRT_DIM_LIGHT_INDEX);
         if constexpr ((FEAT & FEAT_SPHERE) != 0) {
-            if (sv.n_lights > 0 && sv.lights[c.light].gkind == MRT_SHAPE_SPHERE) want_vec = true, vec_dim = MRT_DIM_LIGHT_SPHERE;
+            const int gkind = sv.n_lights == 1 ? as_const(sv.lights)->gkind : (sv.n_lights > 0 ? sv.lights[c.light].gkind : -1);
+            if (gkind == MRT_SHAPE_SPHERE) want_vec = true, vec_dim = MRT_DIM_LIGHT_SPHERE;
         }
     } else if (r == 2 && !has_sun) {
         want_vec = true, vec_dim = MRT_DIM_SKY;
@@ -1777,7 +1782,10 @@ __device__ bool lambertian_generate(SceneRef sv, D3 pdf_normal, double incoming_
     } else if (r == 1) {  // LightPdf::generate, pdf.rs:104-130
         if (sv.n_lights == 0) return false;
         AreaInfo ai;
-        object_generate<(FEAT & ~(FEAT_OCTREE | FEAT_VOLUME))>(sv.lights + c.light, hit_point, incoming_time, g, ua, ub, ai, &unit_vec);
+        constexpr int LF = FEAT & ~(FEAT_OCTREE | FEAT_VOLUME);
+        // (a one-entry list: the light's record is read with scalar loads)
+        if (sv.n_lights == 1) object_generate<LF>(as_const(sv.lights), hit_point, incoming_time, g, ua, ub, ai, &unit_vec);
+        else object_generate<LF>(sv.lights + c.light, hit_point, incoming_time, g, ua, ub, ai, &unit_vec);
         D3 nd = normalize(ai.to_area.d);
         double light_cos = fabs(dot(nd, ai.normal));
         double dist_squared = dot(ai.direction, ai.direction);

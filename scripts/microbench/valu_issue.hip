@@ -68,6 +68,40 @@ KERNEL(k_fma64_salu, REP8("v_fma_f64 v[20:21], v[10:11], v[12:13], v[14:15]", "s
                           "v_fma_f64 v[24:25], v[10:11], v[12:13], v[14:15]", "s_mov_b32 s32, 7",
                           "v_fma_f64 v[26:27], v[10:11], v[12:13], v[14:15]", "s_mov_b32 s33, 9"))
 
+// dependent chains: every instruction reads the result of the one before it (one chain, or two interleaved)
+#define CHAIN1(INS, D, REST) REP8(INS " " D ", " D REST, INS " " D ", " D REST, INS " " D ", " D REST, INS " " D ", " D REST, \
+                                  INS " " D ", " D REST, INS " " D ", " D REST, INS " " D ", " D REST, INS " " D ", " D REST)
+#define CHAIN2(INS, D, E, REST) REP8(INS " " D ", " D REST, INS " " E ", " E REST, INS " " D ", " D REST, INS " " E ", " E REST, \
+                                     INS " " D ", " D REST, INS " " E ", " E REST, INS " " D ", " D REST, INS " " E ", " E REST)
+KERNEL(k_dep_fma64, CHAIN1("v_fma_f64", "v[20:21]", ", v[12:13], v[14:15]"))
+KERNEL(k_dep2_fma64, CHAIN2("v_fma_f64", "v[20:21]", "v[22:23]", ", v[12:13], v[14:15]"))
+KERNEL(k_dep_add64, CHAIN1("v_add_f64", "v[20:21]", ", v[12:13]"))
+KERNEL(k_dep_max64, CHAIN1("v_max_f64", "v[20:21]", ", v[20:21]"))
+KERNEL(k_dep_fma32, CHAIN1("v_fma_f32", "v20", ", v12, v14"))
+KERNEL(k_dep_add32, CHAIN1("v_add_u32", "v20", ", v12"))
+KERNEL(k_dep_rcp64, CHAIN1("v_rcp_f64", "v[20:21]", ""))
+
+template <class K>
+void run_waves(K kern, const char* name, double* out, double clock_ghz) {
+    std::printf("%-28s", name);
+    for (int waves_per_simd = 1; waves_per_simd <= 4; waves_per_simd *= 2) {
+        const int blocks = 256 * 4 * waves_per_simd;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0), hipEventCreate(&e1);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, 0, out, 1.5);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), 0, 0, out, 2.5);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        // cycles a WAVE spends per instruction of its chain
+        std::printf("  %d wave%s/SIMD: %6.2f cycles per instruction of a wave", waves_per_simd, waves_per_simd > 1 ? "s" : " ", ms * 1e6 * clock_ghz / ((double)ITER * 64));
+        hipEventDestroy(e0), hipEventDestroy(e1);
+    }
+    std::printf("\n");
+}
+
 template <class K>
 void run(K kern, const char* name, double* out, double ins_per_body, double clock_ghz) {
     double cyc[2];
@@ -102,6 +136,9 @@ int main() {
     RUN(k_ldexp64, 8), RUN(k_cvt_f64_u32, 8), RUN(k_lshr64, 8), RUN(k_mad_u64_u32, 8);
     RUN(k_fma32, 8), RUN(k_add32, 8), RUN(k_mov32, 8), RUN(k_xor32, 8), RUN(k_cndmask, 8), RUN(k_cndmask_e64, 8), RUN(k_mul_lo, 8), RUN(k_mul_hi, 8), RUN(k_add3, 8);
     RUN(k_cmp_lt64, 8), RUN(k_cmp_class64, 8), RUN(k_cmp_lt32, 8), RUN(k_readlane, 8), RUN(k_salu, 8), RUN(k_fma64_salu, 8);
+#define RUNW(K) run_waves(K, #K, out, ghz)
+    RUNW(k_dep_fma64), RUNW(k_dep2_fma64), RUNW(k_dep_add64), RUNW(k_dep_max64), RUNW(k_dep_fma32), RUNW(k_dep_add32), RUNW(k_dep_rcp64);
+    RUNW(k_fma64), RUNW(k_cndmask_e64);
     hipFree(out);
     return 0;
 }
