@@ -914,6 +914,74 @@ __device__ __forceinline__ bool node_hit(SceneRef sv, RP r, const RayD& ray, D3 
                           inv_world, t_min, t_max, g, medium_dim, oct_entry, t, sub, pos, r->identity == 0 && r->translation != 0);
 }
 
+// A ConstantMedium leaf of the wave-synchronous walk (constant_medium.rs:35-93), evaluated once or -- a span-1
+// node pair folded into one node, NODE_TWICE -- twice: the reference then tests the leaf's box against the bound
+// the first evaluation left and runs Object::hit again, with a fresh draw (bvh.rs:152-161,224-232). The
+// object-space ray and the two boundary hits depend neither on the query range nor on the draw, so they are
+// worked out once and the second evaluation only clamps and draws again (Cornell smoke: one of its two media is
+// such a node; transform and boundary are 210 of the 400 instructions of an evaluation).
+// `pass`: the lanes that passed the box test. Every lane of the wave may call this.
+template <int FEAT, class RP>
+__device__ __forceinline__ void medium_leaf_wave(RP r, int obj, bool twice, bool pass, const RayD& ray, D3 inv_world, const Rng& g,
+                                                 uint32_t& medium_ordinal, double& closest, int& best_obj, int& best_sub) {
+#pragma clang fp contract(off)
+    const double t_min = (double)0.001f;
+    bool ok = pass;
+    double b1 = 0.0, b2 = 0.0, ray_length = 0.0;
+    if (pass) {
+        RayD sr = ray;
+        D3 inv = inv_world;
+        const bool identity = r->identity != 0;
+        if (!identity && r->translation != 0) {
+            sr.o = {ray.o.x + r->to_object.r[0][3], ray.o.y + r->to_object.r[1][3], ray.o.z + r->to_object.r[2][3]};
+        } else if (!identity) {
+            sr = xform_ray(&r->to_object, false, ray);
+            inv = {rcp_fast(sr.d.x), rcp_fast(sr.d.y), rcp_fast(sr.d.z)};
+        }
+        const int k = r->kind2;
+        auto p = &r->p[0];
+        if (k == MRT_SHAPE_RENDER_BOX) {
+            ok = box_hit_twice(p, sr, inv, b1, b2);
+        } else {  // nearest boundary hit in [-1e10, 1e10], then the nearest in [t1 + 1e-4, 1e10] (constant_medium.rs:36-44)
+            double lo = -10000000000.0;
+#pragma nounroll
+            for (int c = 0; c < 2 && ok; ++c) {
+                double th = 0.0;
+                int sh;
+                ok = solid_hit_kp<FEAT>(k, p, sr, inv, lo, 10000000000.0, th, sh);
+                if (c == 0) b1 = th, lo = th + 0.0001;
+                else b2 = th;
+            }
+        }
+        ray_length = sqrt(fma(sr.d.z, sr.d.z, fma(sr.d.y, sr.d.y, sr.d.x * sr.d.x)));
+    }
+    const double neg_inv_density = r->p[9];
+    const int evaluations = twice ? 2 : 1;
+#pragma nounroll
+    for (int e = 0; e < evaluations; ++e) {
+        if (e == 1)
+            pass = pass && aabb_hit(D3{r->bmin[0], r->bmin[1], r->bmin[2]}, D3{r->bmax[0], r->bmax[1], r->bmax[2]}, ray, inv_world, t_min, closest);
+        if (pass) {
+            if (ok) {
+                double t1 = b1, t2 = b2;
+                if (t1 < t_min) t1 = t_min;
+                if (t2 > closest) t2 = closest;
+                if (!(t1 >= t2)) {
+                    if (t1 < 0.0) t1 = 0.0;
+                    const double distance_inside = (t2 - t1) * ray_length;
+                    // rand_scalar(0, 1) is the uniform itself
+                    const double hit_distance = neg_inv_density * log(rng_f64(g, MRT_DIM_MEDIUM + medium_ordinal));
+                    if (!(hit_distance > distance_inside)) {
+                        closest = fma(hit_distance, rcp_fast(ray_length), t1);
+                        best_obj = obj, best_sub = 0;
+                    }
+                }
+            }
+            medium_ordinal++;
+        }
+    }
+}
+
 // Leaf box of a MovingSphere-based object for the time window (t0, t1) the reference passes
 // (bvh.rs:142-145,180; sphere.rs:175-186; hittable.rs:239-282).
 template <class OP, class PP>
@@ -1291,18 +1359,20 @@ __device__ bool nearest_hit_wave(SceneRef sv, const RayD& ray, const Rng& g, boo
             REGION_BEGIN(leaf);
             bool is_medium = false;
             if constexpr ((FEAT & FEAT_MEDIUM) != 0) is_medium = r->kind == MRT_SHAPE_CONSTANT_MEDIUM;
-            if (pass) {
+            if (is_medium) {
+                if constexpr ((FEAT & FEAT_MEDIUM) != 0)
+                    medium_leaf_wave<FEAT>(r, obj, (flags & NODE_TWICE) != 0, pass, ray, inv_d, g, medium_ordinal, closest, best_obj, best_sub);
+            } else if (pass) {
                 double t;
                 int sub;
-                if (node_hit<FEAT>(sv, r, ray, inv_d, t_min, closest, g, MRT_DIM_MEDIUM + medium_ordinal, oct_entry, t, sub, best_pos)) {
+                if (node_hit<FEAT & ~FEAT_MEDIUM>(sv, r, ray, inv_d, t_min, closest, g, 0, oct_entry, t, sub, best_pos)) {
                     closest = t, best_obj = obj, best_sub = sub;
                 }
-                if (is_medium) medium_ordinal++;
             }
             REGION_END(st, is_medium ? ST_MEDIUM_TAIL : ST_LEAF, leaf);
-            // (only stochastic shapes -- media, octrees with volume voxels -- are ever marked)
-            if constexpr ((FEAT & (FEAT_MEDIUM | FEAT_VOLUME)) != 0) {
-                if ((flags & NODE_TWICE) != 0 && !second) {
+            // (of the shapes that are not media only octrees with volume voxels are stochastic and ever marked)
+            if constexpr ((FEAT & FEAT_VOLUME) != 0) {
+                if (!is_medium && (flags & NODE_TWICE) != 0 && !second) {
                     second = true;
                     continue;
                 }

@@ -842,8 +842,10 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
                 } else {
                     std::memcpy(r.p, sh->p, sizeof(r.p));
                 }
+#ifndef MRT_EXP_NO_IMPLIED
                 if (ob.identity && (sh->kind == MRT_SHAPE_XY_RECT || sh->kind == MRT_SHAPE_XZ_RECT || sh->kind == MRT_SHAPE_YZ_RECT))
                     r.flags |= NODE_BOX_IMPLIED;
+#endif
             }
         }
         build_candidate_tree(&s);
