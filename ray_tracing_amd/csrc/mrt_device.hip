@@ -167,6 +167,7 @@ struct RenderParams {
     uint32_t chunk;  // work items a wave claims at a time
     uint32_t all_claimed;  // the global counter had run past the end of the work before this launch
     double inv_npix_strip, inv_strip_w;  // reciprocals for the work-index decomposition
+    double inv_w1, inv_h1;               // 1 / (width - 1), 1 / (height - 1) for camera_ray; NaN: divide
 };
 
 // w -> (w / d, w % d) for w < 2^53, d < 2^32 and a quotient < 2^32, without an integer division:
@@ -1783,6 +1784,18 @@ struct Onb {
     D3 u, v, w;
 };
 __device__ __forceinline__ Onb onb_from_w(D3 n) {
+    // Normals of rectangles, box faces and voxels are unit axis vectors: w is n itself, the cross product with
+    // the helper axis is again a unit axis vector, and both normalisations multiply by exactly 1 -- which is
+    // what the reference computes (cgmath normalize, v * (1 / 1)). When every lane here has such a normal the
+    // two reciprocal square roots are left out.
+    const bool unit_axis = (n.x == 0.0 && n.y == 0.0 && fabs(n.z) == 1.0) || (n.x == 0.0 && fabs(n.y) == 1.0 && n.z == 0.0) ||
+                           (fabs(n.x) == 1.0 && n.y == 0.0 && n.z == 0.0);
+    if (__ballot(!unit_axis) == 0) {
+        D3 a = fabs(n.x) > 0.9 ? D3{0.0, 1.0, 0.0} : D3{1.0, 0.0, 0.0};
+        D3 v = cross(n, a);
+        D3 u = cross(n, v);
+        return {u, v, n};
+    }
     D3 w = normalize(n);
     D3 a = fabs(w.x) > 0.9 ? D3{0.0, 1.0, 0.0} : D3{1.0, 0.0, 0.0};
     D3 v = normalize(cross(w, a));
@@ -1932,26 +1945,41 @@ __device__ F3 background_color(SceneRef sv, const RayD& ray) {
 }
 
 // ============================================================== camera (camera.rs:88-106, ray_tracer.rs:444-447)
+// a / d, correctly rounded, from inv = 1 / d rounded to nearest: the product, then one correction by the exact
+// residual (three instructions for the sixteen of a division). inv = NaN (d is not a normal number): the division.
+__device__ __forceinline__ double div_by(double a, double d, double inv) {
+    if (!(inv == inv)) return a / d;  // (the same for every lane)
+    const double q = a * inv;
+    return fma(fma(-d, q, a), inv, q);
+}
+__host__ __device__ inline double reciprocal_for_div_by(double d) {
+    return (d >= 1.0 && d <= 1e15) ? 1.0 / d : __builtin_nan("");
+}
+// `inv_w1`, `inv_h1`: reciprocal_for_div_by(width - 1), (height - 1)
 __device__ RayD camera_ray(SceneRef sv, uint32_t x, uint32_t y, uint32_t width, uint32_t height,
-                           const Rng& g) {
+                           const Rng& g, double inv_w1, double inv_h1) {
     const auto& c = sv.cam;
-    double s = ((double)x + rand_scalar(g, 0.0, 1.0, MRT_DIM_JITTER_U)) / ((double)width - 1.0);
-    double t = ((double)y + rand_scalar(g, 0.0, 1.0, MRT_DIM_JITTER_V)) / ((double)height - 1.0);
-    D3 p{0.0, 0.0, 0.0};
-    // rand_in_unit_disk (camera.rs:91); with a zero lens radius the sample is multiplied by 0 and
-    // the draws are addressed by dimension, so skipping them changes nothing else
-    for (uint32_t k = 0; c.lens_radius != 0.0 && k < MRT_MAX_REJECT; ++k) {
-        D3 q{rand_scalar(g, -1.0, 1.0, MRT_DIM_LENS + 2 * k), rand_scalar(g, -1.0, 1.0, MRT_DIM_LENS + 2 * k + 1), 0.0};
-        if (dot(q, q) < 1.0) {
-            p = q;
-            break;
-        }
-    }
-    D3 rd = c.lens_radius * p;
-    D3 offset = ld3(c.u) * rd.x + ld3(c.v) * rd.y;
+    double s = div_by((double)x + rand_scalar(g, 0.0, 1.0, MRT_DIM_JITTER_U), (double)width - 1.0, inv_w1);
+    double t = div_by((double)y + rand_scalar(g, 0.0, 1.0, MRT_DIM_JITTER_V), (double)height - 1.0, inv_h1);
     RayD r;
     r.o = ld3(c.origin);
-    r.d = ld3(c.lower_left_corner) + s * ld3(c.horizontal) + t * ld3(c.vertical) - ld3(c.origin) - offset;
+    r.d = ld3(c.lower_left_corner) + s * ld3(c.horizontal) + t * ld3(c.vertical) - ld3(c.origin);
+    // rand_in_unit_disk (camera.rs:91). With a zero lens radius the sample is multiplied by 0, the offset is a
+    // zero vector and subtracting it changes nothing; the draws are addressed by dimension, so skipping them
+    // changes nothing else.
+    if (c.lens_radius != 0.0) {
+        D3 p{0.0, 0.0, 0.0};
+        for (uint32_t k = 0; k < MRT_MAX_REJECT; ++k) {
+            D3 q{rand_scalar(g, -1.0, 1.0, MRT_DIM_LENS + 2 * k), rand_scalar(g, -1.0, 1.0, MRT_DIM_LENS + 2 * k + 1), 0.0};
+            if (dot(q, q) < 1.0) {
+                p = q;
+                break;
+            }
+        }
+        D3 rd = c.lens_radius * p;
+        D3 offset = ld3(c.u) * rd.x + ld3(c.v) * rd.y;
+        r.d = r.d - offset;
+    }
     // rand_scalar(start, end) is start + u * 0 when the shutter interval is empty
     r.time = c.start_time == c.end_time ? c.start_time : rand_scalar(g, c.start_time, c.end_time, MRT_DIM_TIME);
     return r;
@@ -2344,7 +2372,7 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
                 pixel = x + y * rp.width;
                 key = path_key(rp.seed, (uint64_t)pixel, rp.first_sample + sample);
                 Rng g{key, 0};
-                ray = camera_ray(sv, x, y, rp.width, rp.height, g);
+                ray = camera_ray(sv, x, y, rp.width, rp.height, g, rp.inv_w1, rp.inv_h1);
                 thr = {1.f, 1.f, 1.f};
                 seg = 0;
             }
@@ -2454,7 +2482,7 @@ __global__ void __launch_bounds__(BLOCK) k_single_bounce(const SceneView* svp, R
         uint32_t x = rp.x0 + xs;
         pixel = x + y * rp.width;
         key = path_key(rp.seed, (uint64_t)pixel, rp.first_sample + sample);
-        ray = camera_ray(sv, x, y, rp.width, rp.height, Rng(key, 0));
+        ray = camera_ray(sv, x, y, rp.width, rp.height, Rng(key, 0), rp.inv_w1, rp.inv_h1);
     }
     Stamps st{};
     uint32_t rays = live ? 1u : 0u;
@@ -2546,7 +2574,7 @@ __global__ void __launch_bounds__(BLOCK) k_camera_rays(const SceneView* svp, uin
     if (i >= n) return;
     uint32_t x = (uint32_t)pixels[2 * i], y = (uint32_t)pixels[2 * i + 1];
     Rng g{path_key(seed, (uint64_t)x + (uint64_t)y * width, sample), 0};
-    RayD r = camera_ray(sv, x, y, width, height, g);
+    RayD r = camera_ray(sv, x, y, width, height, g, reciprocal_for_div_by((double)width - 1.0), reciprocal_for_div_by((double)height - 1.0));
     double* o = out + 7 * (size_t)i;
     o[0] = r.o.x, o[1] = r.o.y, o[2] = r.o.z, o[3] = r.d.x, o[4] = r.d.y, o[5] = r.d.z, o[6] = r.time;
 }
@@ -2933,6 +2961,7 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
     rp.n_work = rp.npix_strip * spp;
     rp.inv_npix_strip = 1.0 / (double)rp.npix_strip;
     rp.inv_strip_w = 1.0 / (double)strip_w;
+    rp.inv_w1 = reciprocal_for_div_by((double)width - 1.0), rp.inv_h1 = reciprocal_for_div_by((double)height - 1.0);
     rp.seed = seed, rp.first_sample = first_sample;
     rp.steps = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(sc->opt_steps, 65536));
     uint32_t n_slots = (uint32_t)std::min<unsigned long long>(pool_slots, (rp.n_work + BLOCK - 1) / BLOCK * BLOCK);
