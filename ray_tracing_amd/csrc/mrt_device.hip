@@ -238,6 +238,33 @@ __device__ __forceinline__ D3 normalize(D3 a) {
     if (__builtin_expect(!(d2 > 1e-300 && d2 < 1e300), 0)) inv = 1.0 / sqrt(d2);  // zero, huge, NaN: IEEE path
     return a * inv;
 }
+// Natural logarithm of a uniform draw u = k * 2^-53, 0 <= u < 1 (the free-path draw of a medium,
+// constant_medium.rs:74-75), by the classic argument reduction u = m * 2^e with m in [sqrt(1/2), sqrt(2)),
+// s = (m - 1) / (m + 1), log m = 2 atanh s as a degree-7 polynomial in s^2 (the fdlibm kernel and coefficients;
+// error below 1 ulp with an exact quotient, about 1.5 ulp with the refined reciprocal used here). 37 instructions
+// for the library routine's 101, which works in double-double to stay below 1 ulp for every argument; a medium
+// visit draws once and a Cornell smoke segment holds three visits. log(0) = -inf.
+__device__ __forceinline__ double log_unit(double u) {
+    double m = __builtin_amdgcn_frexp_mant(u);  // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(u);
+    const bool low = m < 0.70710678118654752;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double f = m - 1.0;
+    const double d = 2.0 + f;  // in [1.7, 2.42): no special cases
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(r, fma(-d, r, 1.0), r);
+    r = fma(r, fma(-d, r, 1.0), r);
+    const double sq = f * r;
+    const double dk = (double)e;
+    const double z = sq * sq, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double big_r = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double res = dk * 6.93147180369123816490e-01 - ((hfsq - fma(sq, hfsq + big_r, dk * 1.90821492927058770002e-10)) - f);
+    return u == 0.0 ? -INFINITY : res;
+}
 constexpr double INV_PI = 0.31830988618379067154;
 __device__ __forceinline__ double comp(D3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 template <class P>
@@ -430,6 +457,37 @@ __device__ __forceinline__ bool sphere_hit(D3 c, double radius, const RayD& r, d
         if (root < t_min || t_max < root) return false;
     }
     t_out = root;
+    return true;
+}
+// The two boundary queries of a medium around a Sphere (constant_medium.rs:36-44): sphere_hit over
+// [-1e10, 1e10], then over [t1 + 1e-4, 1e10]. Both answers are roots of the same quadratic, so the discriminant,
+// its square root and the reciprocal are worked out once; the choice of the root is sphere_hit's, per query.
+__device__ __forceinline__ bool sphere_hit_twice(D3 c, double radius, const RayD& r, double& t1, double& t2) {
+#pragma clang fp contract(off)
+    const double rx = r.o.x - c.x, ry = r.o.y - c.y, rz = r.o.z - c.z;
+    double a = fma(r.d.z, r.d.z, fma(r.d.y, r.d.y, r.d.x * r.d.x));
+    double half_b = fma(rz, r.d.z, fma(ry, r.d.y, rx * r.d.x));
+    double cc = fma(-radius, radius, fma(rz, rz, fma(ry, ry, rx * rx)));
+    double disc = fma(-a, cc, half_b * half_b);
+    if (disc < 0.0) return false;
+    double sq = sqrt(disc);
+    double inv_a = rcp_fast(a);
+    const double near_root = (-half_b - sq) * inv_a, far_root = (-half_b + sq) * inv_a;
+    const double hi = 10000000000.0;
+    double lo = -10000000000.0;
+    double root = near_root;
+    if (root < lo || hi < root) {
+        root = far_root;
+        if (root < lo || hi < root) return false;
+    }
+    t1 = root;
+    lo = root + 0.0001;
+    root = near_root;
+    if (root < lo || hi < root) {
+        root = far_root;
+        if (root < lo || hi < root) return false;
+    }
+    t2 = root;
     return true;
 }
 // sphere.rs:139-142
@@ -891,7 +949,7 @@ __device__ __forceinline__ bool leaf_hit(SceneRef sv, int kind, int bkind, int o
         double len2 = fma(sr.d.z, sr.d.z, fma(sr.d.y, sr.d.y, sr.d.x * sr.d.x));
         double ray_length = sqrt(len2);
         double distance_inside = (t2 - t1) * ray_length;
-        double hit_distance = neg_inv_density * log(rng_f64(g, medium_dim));  // rand_scalar(0, 1) is the uniform itself
+        double hit_distance = neg_inv_density * log_unit(rng_f64(g, medium_dim));  // rand_scalar(0, 1) is the uniform itself
         if (hit_distance > distance_inside) return false;
         t = fma(hit_distance, rcp_fast(ray_length), t1);
         return true;
@@ -943,6 +1001,8 @@ __device__ __forceinline__ void medium_leaf_wave(RP r, int obj, bool twice, bool
         auto p = &r->p[0];
         if (k == MRT_SHAPE_RENDER_BOX) {
             ok = box_hit_twice(p, sr, inv, b1, b2);
+        } else if ((FEAT & FEAT_SPHERE) != 0 && k == MRT_SHAPE_SPHERE) {
+            ok = sphere_hit_twice(D3{p[1], p[2], p[3]}, p[0], sr, b1, b2);
         } else {  // nearest boundary hit in [-1e10, 1e10], then the nearest in [t1 + 1e-4, 1e10] (constant_medium.rs:36-44)
             double lo = -10000000000.0;
 #pragma nounroll
@@ -971,7 +1031,7 @@ __device__ __forceinline__ void medium_leaf_wave(RP r, int obj, bool twice, bool
                     if (t1 < 0.0) t1 = 0.0;
                     const double distance_inside = (t2 - t1) * ray_length;
                     // rand_scalar(0, 1) is the uniform itself
-                    const double hit_distance = neg_inv_density * log(rng_f64(g, MRT_DIM_MEDIUM + medium_ordinal));
+                    const double hit_distance = neg_inv_density * log_unit(rng_f64(g, MRT_DIM_MEDIUM + medium_ordinal));
                     if (!(hit_distance > distance_inside)) {
                         closest = fma(hit_distance, rcp_fast(ray_length), t1);
                         best_obj = obj, best_sub = 0;
