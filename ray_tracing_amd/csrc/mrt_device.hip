@@ -1396,13 +1396,30 @@ __device__ bool nearest_hit_wave(SceneRef sv, const RayD& ray, const Rng& g, boo
         const int obj = r->object;
         const int flags = r->flags;
         const int skip = r->skip;
+        const int kind_at_top = r->kind;
+        const double a0_at_top = r->p[0], a1_at_top = r->p[1], b0_at_top = r->p[2], b1_at_top = r->p[3], k_at_top = r->p[4];
+        asm volatile("" ::"s"(obj), "s"(kind_at_top), "s"(a0_at_top), "s"(a1_at_top), "s"(b0_at_top), "s"(b1_at_top), "s"(k_at_top));
+        if ((flags & NODE_BOX_IMPLIED) != 0) {
+            // An untransformed rectangle: its shape test decides by itself, and all it reads is the five
+            // parameters. Left to the compiler the leaf is three round trips to the scalar cache, one behind the
+            // other (links and flags; kind and transform class; parameters) around two dozen instructions.
+            if (i >= resume) {
+                const int kind = kind_at_top;
+                const double a0 = a0_at_top, a1 = a1_at_top, b0 = b0_at_top, b1 = b1_at_top, k = k_at_top;
+                double t;
+                const bool hit = kind == MRT_SHAPE_XY_RECT   ? rect_hit<2>(a0, a1, b0, b1, k, ray, inv_d, t_min, closest, t)
+                                 : kind == MRT_SHAPE_XZ_RECT ? rect_hit<1>(a0, a1, b0, b1, k, ray, inv_d, t_min, closest, t)
+                                                             : rect_hit<0>(a0, a1, b0, b1, k, ray, inv_d, t_min, closest, t);
+                if (hit) closest = t, best_obj = obj, best_sub = 0;
+            }
+            i = i + 1;
+            continue;
+        }
         bool pass = false;
         if (i >= resume) {
             bool dynamic = false;
             if constexpr ((FEAT & FEAT_MOVING) != 0) dynamic = (flags & NODE_DYNAMIC_BOX) != 0;
-            if ((flags & NODE_BOX_IMPLIED) != 0) {
-                pass = true;  // the leaf's shape test decides (an untransformed rectangle)
-            } else if (dynamic) {
+            if (dynamic) {
                 D3 mn, mx;
                 dynamic_leaf_box(as_const(sv.objects) + obj, r->p, r->identity != 0, t_min, closest, mn, mx);
                 pass = aabb_hit(mn, mx, ray, inv_d, t_min, closest);
