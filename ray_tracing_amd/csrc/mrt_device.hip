@@ -964,13 +964,15 @@ __device__ __forceinline__ bool object_hit(SceneRef sv, OP ob, const RayD& ray, 
     return leaf_hit<FEAT>(sv, ob->kind, ob->gkind, ob->octree, &ob->p[0], ob->p[9], ob->identity != 0, &ob->to_object, ray,
                           inv_world, t_min, t_max, g, medium_dim, oct_entry, t, sub, pos);
 }
-// Leaf test of the wave-synchronous walk from a self-contained node record (scalar operands).
+// Leaf test of the wave-synchronous walk from a self-contained node record (scalar operands). `kind` and `flags`
+// are the record's, which the walk holds already.
 template <int FEAT, class RP>
-__device__ __forceinline__ bool node_hit(SceneRef sv, RP r, const RayD& ray, D3 inv_world, double t_min,
+__device__ __forceinline__ bool node_hit(SceneRef sv, RP r, int kind, int flags, const RayD& ray, D3 inv_world, double t_min,
                                          double t_max, const Rng& g, uint32_t medium_dim, uint32_t& oct_entry, double& t,
                                          int& sub, D3& pos) {
-    return leaf_hit<FEAT>(sv, r->kind, r->kind2, r->octree, &r->p[0], r->p[9], r->identity != 0, &r->to_object, ray,
-                          inv_world, t_min, t_max, g, medium_dim, oct_entry, t, sub, pos, r->identity == 0 && r->translation != 0);
+    const bool identity = (flags & NODE_IDENTITY) != 0;
+    return leaf_hit<FEAT>(sv, kind, (flags >> NODE_KIND2_SHIFT) & 0xFF, r->octree, &r->p[0], r->p[9], identity, &r->to_object, ray,
+                          inv_world, t_min, t_max, g, medium_dim, oct_entry, t, sub, pos, !identity && (flags & NODE_TRANSLATION) != 0);
 }
 
 // A ConstantMedium leaf of the wave-synchronous walk (constant_medium.rs:35-93), evaluated once or -- a span-1
@@ -981,7 +983,7 @@ __device__ __forceinline__ bool node_hit(SceneRef sv, RP r, const RayD& ray, D3 
 // such a node; transform and boundary are 210 of the 400 instructions of an evaluation).
 // `pass`: the lanes that passed the box test. Every lane of the wave may call this.
 template <int FEAT, class RP>
-__device__ __forceinline__ void medium_leaf_wave(RP r, int obj, bool twice, bool pass, const RayD& ray, D3 inv_world, const Rng& g,
+__device__ __forceinline__ void medium_leaf_wave(RP r, int obj, int flags, bool pass, const RayD& ray, D3 inv_world, const Rng& g,
                                                  uint32_t& medium_ordinal, double& closest, int& best_obj, int& best_sub) {
 #pragma clang fp contract(off)
     const double t_min = (double)0.001f;
@@ -990,14 +992,14 @@ __device__ __forceinline__ void medium_leaf_wave(RP r, int obj, bool twice, bool
     if (pass) {
         RayD sr = ray;
         D3 inv = inv_world;
-        const bool identity = r->identity != 0;
-        if (!identity && r->translation != 0) {
+        const bool identity = (flags & NODE_IDENTITY) != 0;
+        if (!identity && (flags & NODE_TRANSLATION) != 0) {
             sr.o = {ray.o.x + r->to_object.r[0][3], ray.o.y + r->to_object.r[1][3], ray.o.z + r->to_object.r[2][3]};
         } else if (!identity) {
             sr = xform_ray(&r->to_object, false, ray);
             inv = {rcp_fast(sr.d.x), rcp_fast(sr.d.y), rcp_fast(sr.d.z)};
         }
-        const int k = r->kind2;
+        const int k = (flags >> NODE_KIND2_SHIFT) & 0xFF;
         auto p = &r->p[0];
         if (k == MRT_SHAPE_RENDER_BOX) {
             ok = box_hit_twice(p, sr, inv, b1, b2);
@@ -1017,7 +1019,7 @@ __device__ __forceinline__ void medium_leaf_wave(RP r, int obj, bool twice, bool
         ray_length = sqrt(fma(sr.d.z, sr.d.z, fma(sr.d.y, sr.d.y, sr.d.x * sr.d.x)));
     }
     const double neg_inv_density = r->p[9];
-    const int evaluations = twice ? 2 : 1;
+    const int evaluations = (flags & NODE_TWICE) != 0 ? 2 : 1;
 #pragma nounroll
     for (int e = 0; e < evaluations; ++e) {
         if (e == 1)
@@ -1421,7 +1423,7 @@ __device__ bool nearest_hit_wave(SceneRef sv, const RayD& ray, const Rng& g, boo
             if constexpr ((FEAT & FEAT_MOVING) != 0) dynamic = (flags & NODE_DYNAMIC_BOX) != 0;
             if (dynamic) {
                 D3 mn, mx;
-                dynamic_leaf_box(as_const(sv.objects) + obj, r->p, r->identity != 0, t_min, closest, mn, mx);
+                dynamic_leaf_box(as_const(sv.objects) + obj, r->p, (flags & NODE_IDENTITY) != 0, t_min, closest, mn, mx);
                 pass = aabb_hit(mn, mx, ray, inv_d, t_min, closest);
             } else {
                 pass = aabb_hit(D3{r->bmin[0], r->bmin[1], r->bmin[2]}, D3{r->bmax[0], r->bmax[1], r->bmax[2]}, ray, inv_d, t_min, closest);
@@ -1436,14 +1438,14 @@ __device__ bool nearest_hit_wave(SceneRef sv, const RayD& ray, const Rng& g, boo
         if (obj >= 0) {
             REGION_BEGIN(leaf);
             bool is_medium = false;
-            if constexpr ((FEAT & FEAT_MEDIUM) != 0) is_medium = r->kind == MRT_SHAPE_CONSTANT_MEDIUM;
+            if constexpr ((FEAT & FEAT_MEDIUM) != 0) is_medium = kind_at_top == MRT_SHAPE_CONSTANT_MEDIUM;
             if (is_medium) {
                 if constexpr ((FEAT & FEAT_MEDIUM) != 0)
-                    medium_leaf_wave<FEAT>(r, obj, (flags & NODE_TWICE) != 0, pass, ray, inv_d, g, medium_ordinal, closest, best_obj, best_sub);
+                    medium_leaf_wave<FEAT>(r, obj, flags, pass, ray, inv_d, g, medium_ordinal, closest, best_obj, best_sub);
             } else if (pass) {
                 double t;
                 int sub;
-                if (node_hit<FEAT & ~FEAT_MEDIUM>(sv, r, ray, inv_d, t_min, closest, g, 0, oct_entry, t, sub, best_pos)) {
+                if (node_hit<FEAT & ~FEAT_MEDIUM>(sv, r, kind_at_top, flags, ray, inv_d, t_min, closest, g, 0, oct_entry, t, sub, best_pos)) {
                     closest = t, best_obj = obj, best_sub = sub;
                 }
             }

@@ -83,7 +83,13 @@ enum : int32_t {
     // query range and its point inside the rectangle's extent, so every slab interval contains it. The wave walk
     // goes straight to the shape. (Within rounding of the rectangle's edge the two tests are computed from
     // different roundings of the same quantity -- there the answer depends on rounding with or without the box.)
-    NODE_BOX_IMPLIED = 4
+    NODE_BOX_IMPLIED = 4,
+    // (DNodeRec only) what the leaf test branches on, next to the flags so that it arrives with the links: the
+    // object transform is the identity / a pure translation (linear part exactly the identity), and in bits 8..15
+    // the kind of a medium's boundary shape
+    NODE_IDENTITY = 8,
+    NODE_TRANSLATION = 16,
+    NODE_KIND2_SHIFT = 8
 };
 
 // Candidate search: largest tree (nodes) it handles -- one bit per node and lane in LDS -- and the
