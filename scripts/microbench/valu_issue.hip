@@ -49,7 +49,6 @@ KERNEL(k_fma32, BODY32("v_fma_f32", "v10, v12, v14"))
 KERNEL(k_add32, BODY32("v_add_u32", "v10, v12"))
 KERNEL(k_mov32, BODY32("v_mov_b32", "v10"))
 KERNEL(k_xor32, BODY32("v_xor_b32", "v10, v12"))
-KERNEL(k_cndmask, BODY32("v_cndmask_b32", "v10, v12, vcc"))
 KERNEL(k_cndmask_e64, BODY32("v_cndmask_b32", "v10, v12, s[36:37]"))
 KERNEL(k_mul_lo, BODY32("v_mul_lo_u32", "v10, v12"))
 KERNEL(k_mul_hi, BODY32("v_mul_hi_u32", "v10, v12"))
@@ -59,15 +58,6 @@ KERNEL(k_cmp_class64, BODYCMP("v_cmp_class_f64", "v[10:11], v12"))
 KERNEL(k_cmp_lt32, BODYCMP("v_cmp_lt_i32", "v10, v12"))
 KERNEL(k_readlane, REP8("v_readlane_b32 s20, v10, 3", "v_readlane_b32 s21, v11, 3", "v_readlane_b32 s22, v12, 3", "v_readlane_b32 s23, v13, 3",
                         "v_readlane_b32 s24, v10, 5", "v_readlane_b32 s25, v11, 5", "v_readlane_b32 s26, v12, 5", "v_readlane_b32 s27, v13, 5"))
-KERNEL(k_salu, REP8("s_and_b64 s[20:21], s[22:23], s[24:25]", "s_or_b64 s[26:27], s[22:23], s[24:25]", "s_and_b64 s[28:29], s[22:23], s[24:25]",
-                    "s_or_b64 s[30:31], s[22:23], s[24:25]", "s_mov_b32 s32, 7", "s_mov_b32 s33, 9", "s_and_b64 s[34:35], s[22:23], s[24:25]",
-                    "s_or_b64 s[20:21], s[22:23], s[24:25]"))
-// a vector instruction next to a scalar one: do they share the issue slot of a wave?
-KERNEL(k_fma64_salu, REP8("v_fma_f64 v[20:21], v[10:11], v[12:13], v[14:15]", "s_and_b64 s[20:21], s[22:23], s[24:25]",
-                          "v_fma_f64 v[22:23], v[10:11], v[12:13], v[14:15]", "s_or_b64 s[26:27], s[22:23], s[24:25]",
-                          "v_fma_f64 v[24:25], v[10:11], v[12:13], v[14:15]", "s_mov_b32 s32, 7",
-                          "v_fma_f64 v[26:27], v[10:11], v[12:13], v[14:15]", "s_mov_b32 s33, 9"))
-
 // dependent chains: every instruction reads the result of the one before it (one chain, or two interleaved)
 #define CHAIN1(INS, D, REST) REP8(INS " " D ", " D REST, INS " " D ", " D REST, INS " " D ", " D REST, INS " " D ", " D REST, \
                                   INS " " D ", " D REST, INS " " D ", " D REST, INS " " D ", " D REST, INS " " D ", " D REST)
@@ -134,8 +124,8 @@ int main() {
 #define RUN(K, N) run(K, #K, out, N, ghz)
     RUN(k_fma64, 8), RUN(k_add64, 8), RUN(k_mul64, 8), RUN(k_min64, 8), RUN(k_max64, 8), RUN(k_mov64, 8), RUN(k_rcp64, 8), RUN(k_rsq64, 8);
     RUN(k_ldexp64, 8), RUN(k_cvt_f64_u32, 8), RUN(k_lshr64, 8), RUN(k_mad_u64_u32, 8);
-    RUN(k_fma32, 8), RUN(k_add32, 8), RUN(k_mov32, 8), RUN(k_xor32, 8), RUN(k_cndmask, 8), RUN(k_cndmask_e64, 8), RUN(k_mul_lo, 8), RUN(k_mul_hi, 8), RUN(k_add3, 8);
-    RUN(k_cmp_lt64, 8), RUN(k_cmp_class64, 8), RUN(k_cmp_lt32, 8), RUN(k_readlane, 8), RUN(k_salu, 8), RUN(k_fma64_salu, 8);
+    RUN(k_fma32, 8), RUN(k_add32, 8), RUN(k_mov32, 8), RUN(k_xor32, 8), RUN(k_cndmask_e64, 8), RUN(k_mul_lo, 8), RUN(k_mul_hi, 8), RUN(k_add3, 8);
+    RUN(k_cmp_lt64, 8), RUN(k_cmp_class64, 8), RUN(k_cmp_lt32, 8), RUN(k_readlane, 8);
 #define RUNW(K) run_waves(K, #K, out, ghz)
     RUNW(k_dep_fma64), RUNW(k_dep2_fma64), RUNW(k_dep_add64), RUNW(k_dep_max64), RUNW(k_dep_fma32), RUNW(k_dep_add32), RUNW(k_dep_rcp64);
     RUNW(k_fma64), RUNW(k_cndmask_e64);
