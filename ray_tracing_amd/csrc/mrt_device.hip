@@ -1409,9 +1409,14 @@ __device__ bool nearest_hit_wave(SceneRef sv, const RayD& ray, const Rng& g, boo
                 const int kind = kind_at_top;
                 const double a0 = a0_at_top, a1 = a1_at_top, b0 = b0_at_top, b1 = b1_at_top, k = k_at_top;
                 double t;
-                const bool hit = kind == MRT_SHAPE_XY_RECT   ? rect_hit<2>(a0, a1, b0, b1, k, ray, inv_d, t_min, closest, t)
+                bool hit = kind == MRT_SHAPE_XY_RECT   ? rect_hit<2>(a0, a1, b0, b1, k, ray, inv_d, t_min, closest, t)
                                  : kind == MRT_SHAPE_XZ_RECT ? rect_hit<1>(a0, a1, b0, b1, k, ray, inv_d, t_min, closest, t)
                                                              : rect_hit<0>(a0, a1, b0, b1, k, ray, inv_d, t_min, closest, t);
+                // (A ray lying in the rectangle's plane "hits" it at t = 0 * inf = NaN, which passes every
+                // comparison of the shape test; the box test is what rejects such a ray when it misses the
+                // rectangle's extent, so a NaN hit still takes it.)
+                if (hit && t != t)
+                    hit = aabb_hit(D3{r->bmin[0], r->bmin[1], r->bmin[2]}, D3{r->bmax[0], r->bmax[1], r->bmax[2]}, ray, inv_d, t_min, closest);
                 if (hit) closest = t, best_obj = obj, best_sub = 0;
             }
             i = i + 1;
