@@ -208,6 +208,26 @@ def test_rays_at_rectangle_borders(worlds, name):
     np.testing.assert_allclose(ng[hit], no[hit], rtol=0, atol=N_ATOL)
 
 
+@pytest.mark.parametrize("name", ["Cornell Smoke", "Easy Scene", "Easy Cornell Box", "Fast Oct Tree Volume Ice", "Two Sphere"])
+def test_wave_walk_equals_per_lane_walk(worlds, name):
+    """The wave-synchronous walk has its own leaf code for media (boundary worked out once, second evaluation of a
+    twice-evaluated medium from the same boundary hits) and rectangles; the per-lane walk runs the generic leaf test
+    with its two-round loops. Same arithmetic, same draw numbering: ids and t must be equal bit for bit."""
+    info, rt, ow = worlds(name)
+    rays = probe_rays(ow, info, n_camera=30000, n_random=90000, seed=33)
+    og, tg, ng, pg, fg = rt.world.trace_rays(rays, seed=13)
+    rt.world.set_option("traversal", 1)
+    try:
+        ol, tl, nl, pl, fl = rt.world.trace_rays(rays, seed=13)
+    finally:
+        rt.world.set_option("traversal", 0)
+    assert (og == ol).all(), f"{int((og != ol).sum())} ids differ"
+    hit = ol >= 0
+    assert hit.sum() > 10000
+    assert np.array_equal(tg[hit], tl[hit])
+    assert np.array_equal(ng[hit], nl[hit])
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_tier_p_golden_image(worlds, name):
     info, rt, ow = worlds(name, seed=3)
