@@ -193,7 +193,8 @@ enum : int {
     FEAT_PERLIN = 64,   // Perlin textures (implies FEAT_TEXTURE)
     FEAT_VOLUME = 128,  // volume / reflecting voxels in an octree (implies FEAT_OCTREE)
     FEAT_MOVING = 256,  // MovingSphere shapes (implies FEAT_SPHERE): centre by ray time, leaf boxes that depend on the query
-    FEAT_ALL = 511
+    FEAT_SPHERE_LEAF = 512,  // an untransformed Sphere as an object of its own (implies FEAT_SPHERE): direct leaf test in the wave walk
+    FEAT_ALL = 1023
 };
 
 // ============================================================== small vector math
@@ -1389,6 +1390,7 @@ __device__ bool nearest_hit_wave(SceneRef sv, const RayD& ray, const Rng& g, boo
     auto recs = as_const(sv.node_recs);
     int resume = live ? 0 : n;
     int i = 0;
+    const bool axis_parallel = ray.d.x == 0.0 || ray.d.y == 0.0 || ray.d.z == 0.0;
     // (wave-uniform) the node at hand is a NODE_TWICE node on its second evaluation. The second evaluation is one
     // more turn of this loop on the same node -- box test against the updated bound by the lanes that passed the
     // first, then the leaf -- so that the loop body holds one box test and one leaf test.
@@ -1402,20 +1404,26 @@ __device__ bool nearest_hit_wave(SceneRef sv, const RayD& ray, const Rng& g, boo
         const double a0_at_top = r->p[0], a1_at_top = r->p[1], b0_at_top = r->p[2], b1_at_top = r->p[3], k_at_top = r->p[4];
         asm volatile("" ::"s"(obj), "s"(kind_at_top), "s"(a0_at_top), "s"(a1_at_top), "s"(b0_at_top), "s"(b1_at_top), "s"(k_at_top));
         if ((flags & NODE_BOX_IMPLIED) != 0) {
-            // An untransformed rectangle: its shape test decides by itself, and all it reads is the five
-            // parameters. Left to the compiler the leaf is three round trips to the scalar cache, one behind the
+            // An untransformed rectangle or sphere: its shape test decides by itself, and all it reads is its
+            // five (four) parameters. Left to the compiler the leaf is three round trips to the scalar cache, one behind the
             // other (links and flags; kind and transform class; parameters) around two dozen instructions.
             if (i >= resume) {
                 const int kind = kind_at_top;
                 const double a0 = a0_at_top, a1 = a1_at_top, b0 = b0_at_top, b1 = b1_at_top, k = k_at_top;
                 double t;
-                bool hit = kind == MRT_SHAPE_XY_RECT   ? rect_hit<2>(a0, a1, b0, b1, k, ray, inv_d, t_min, closest, t)
-                                 : kind == MRT_SHAPE_XZ_RECT ? rect_hit<1>(a0, a1, b0, b1, k, ray, inv_d, t_min, closest, t)
-                                                             : rect_hit<0>(a0, a1, b0, b1, k, ray, inv_d, t_min, closest, t);
+                bool hit;
+                if ((FEAT & FEAT_SPHERE_LEAF) != 0 && kind == MRT_SHAPE_SPHERE)  // (parameters: radius, centre)
+                    hit = sphere_hit(D3{a1, b0, b1}, a0, ray, t_min, closest, t);
+                else
+                    hit = kind == MRT_SHAPE_XY_RECT   ? rect_hit<2>(a0, a1, b0, b1, k, ray, inv_d, t_min, closest, t)
+                          : kind == MRT_SHAPE_XZ_RECT ? rect_hit<1>(a0, a1, b0, b1, k, ray, inv_d, t_min, closest, t)
+                                                      : rect_hit<0>(a0, a1, b0, b1, k, ray, inv_d, t_min, closest, t);
                 // (A ray lying in the rectangle's plane "hits" it at t = 0 * inf = NaN, which passes every
-                // comparison of the shape test; the box test is what rejects such a ray when it misses the
-                // rectangle's extent, so a NaN hit still takes it.)
-                if (hit && t != t)
+                // comparison of the shape test -- so does a sphere's NaN discriminant; the box test is what rejects
+                // such a ray, so a NaN hit still takes it. So does a sphere's hit by a ray with a zero direction
+                // component: such a ray can run along a face of the box, outside by one ulp, and still graze the
+                // sphere within rounding. A rectangle's test is exact for it: the coordinate does not move.)
+                if (hit && (t != t || ((FEAT & FEAT_SPHERE_LEAF) != 0 && kind == MRT_SHAPE_SPHERE && axis_parallel)))
                     hit = aabb_hit(D3{r->bmin[0], r->bmin[1], r->bmin[2]}, D3{r->bmax[0], r->bmax[1], r->bmax[2]}, ray, inv_d, t_min, closest);
                 if (hit) closest = t, best_obj = obj, best_sub = 0;
             }
@@ -2820,10 +2828,10 @@ struct mrt_scene {
 template <int... M>
 struct FeatList {};
 constexpr int FEAT_NO_OCTREE = FEAT_ALL & ~(FEAT_OCTREE | FEAT_VOLUME);
-using KernelFeats = FeatList<0, FEAT_MEDIUM, FEAT_SPHERE | FEAT_MEDIUM, FEAT_SPHERE | FEAT_MOVING | FEAT_SPECULAR | FEAT_SKY,
-                             FEAT_SPHERE | FEAT_SPECULAR | FEAT_TEXTURE | FEAT_SKY,
-                             FEAT_NO_OCTREE, FEAT_OCTREE | FEAT_SKY, FEAT_OCTREE | FEAT_SPHERE | FEAT_SKY,
-                             FEAT_OCTREE | FEAT_VOLUME | FEAT_SPHERE | FEAT_SKY, FEAT_ALL>;
+using KernelFeats = FeatList<0, FEAT_MEDIUM, FEAT_SPHERE | FEAT_MEDIUM, FEAT_SPHERE | FEAT_SPHERE_LEAF | FEAT_MOVING | FEAT_SPECULAR | FEAT_SKY,
+                             FEAT_SPHERE | FEAT_SPHERE_LEAF | FEAT_SPECULAR | FEAT_TEXTURE | FEAT_SKY,
+                             FEAT_NO_OCTREE, FEAT_OCTREE | FEAT_SKY, FEAT_OCTREE | FEAT_SPHERE | FEAT_SPHERE_LEAF | FEAT_SKY,
+                             FEAT_OCTREE | FEAT_VOLUME | FEAT_SPHERE | FEAT_SPHERE_LEAF | FEAT_SKY, FEAT_ALL>;
 // The single-bounce shaders (debug views) are instantiated for two sets only.
 using SingleBounceFeats = FeatList<FEAT_NO_OCTREE, FEAT_ALL>;
 // Calls f(std::integral_constant<int, M>) for the first instantiated set M that covers `need`.
@@ -2843,6 +2851,8 @@ static int scene_features(const FlatScene& f) {
         if (sh.kind == MRT_SHAPE_MOVING_SPHERE) need |= FEAT_MOVING;
         if (sh.kind == MRT_SHAPE_CONSTANT_MEDIUM) need |= FEAT_MEDIUM;
     }
+    for (const DObject& ob : f.objects)
+        if (f.shapes[(size_t)ob.shape].kind == MRT_SHAPE_SPHERE && ob.identity) need |= FEAT_SPHERE_LEAF;
     for (const DMaterial& m : f.materials)
         if (m.kind == MRT_MAT_METAL || m.kind == MRT_MAT_DIELECTRIC) need |= FEAT_SPECULAR;
     for (const DTexture& t : f.textures)

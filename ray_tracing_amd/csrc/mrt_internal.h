@@ -78,11 +78,13 @@ struct DCamera {
 enum : int32_t {
     NODE_DYNAMIC_BOX = 1,  // leaf whose box depends on (t_min, t_max): MovingSphere (bvh.rs:142-145,180)
     NODE_TWICE = 2,        // span-1 leaf pair folded into one node; evaluate the object twice (bvh.rs:224-232)
-    // (DNodeRec only) leaf whose shape test implies its box test: an untransformed rectangle. Its box is the
-    // rectangle itself, 0.002 thick (rect.rs:88-93,208-213,333-338); a hit has its parameter inside the
-    // query range and its point inside the rectangle's extent, so every slab interval contains it. The wave walk
-    // goes straight to the shape. (Within rounding of the rectangle's edge the two tests are computed from
-    // different roundings of the same quantity -- there the answer depends on rounding with or without the box.)
+    // (DNodeRec only) leaf whose shape test implies its box test: an untransformed rectangle or sphere. A
+    // rectangle's box is the rectangle itself, 0.002 thick (rect.rs:88-93,208-213,333-338), a sphere's is centre
+    // +- radius (sphere.rs:57-62); a hit has its parameter inside the query range and its point on the shape, so
+    // every slab interval contains it. The wave walk goes straight to the shape. (Within rounding of a rectangle's
+    // edge, or of the six points where a sphere touches its box, the two tests are computed from different roundings
+    // of the same quantity -- there the answer depends on rounding with or without the box. A hit at t = NaN is no
+    // such hit and still takes the box test.)
     NODE_BOX_IMPLIED = 4,
     // (DNodeRec only) what the leaf test branches on, next to the flags so that it arrives with the links: the
     // object transform is the identity / a pure translation (linear part exactly the identity), and in bits 8..15
