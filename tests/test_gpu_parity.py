@@ -165,13 +165,38 @@ def rectangle_border_rays(info, per_rect: int, seed: int) -> np.ndarray:
             if not np.any(d):
                 continue
             rays.append(np.concatenate([origin, d * (0.5 + rng.random()), [0.0]]))
+    # untransformed spheres: axis-parallel rays along the faces of the sphere's box (tangent to the sphere at the
+    # point where it touches the face), exactly, one ulp inside and one ulp outside; and rays from random origins
+    # through the six touching points
+    from ray_tracing_amd.scene import Sphere
+    for ob in info.objects:
+        sh = ob.shape
+        if not isinstance(sh, Sphere) or not np.array_equal(ob.transform.world_transform, np.eye(4)):
+            continue
+        ctr, rad = np.array(sh.origin, dtype=np.float64), abs(float(sh.radius))
+        for _ in range(per_rect // 2):
+            face_axis, run_axis = rng.permutation(3)[:2]
+            touch = ctr.copy()
+            touch[face_axis] += rad * (1.0 if rng.random() < 0.5 else -1.0)
+            nudge = int(rng.integers(0, 3))
+            if nudge:
+                touch[face_axis] = np.nextafter(touch[face_axis], np.inf if nudge == 1 else -np.inf)
+            if rng.random() < 0.6:
+                origin = touch.copy()
+                origin[run_axis] += (rng.random() - 0.5) * 6.0 * max(rad, 1.0)
+                d = np.zeros(3)
+                d[run_axis] = (touch[run_axis] - origin[run_axis]) or 1.0
+            else:
+                origin = c + (rng.random(3) - 0.5) * r * 0.9
+                d = touch - origin
+            rays.append(np.concatenate([origin, d * (0.5 + rng.random()), [0.0]]))
     return np.asarray(rays, dtype=np.float64).reshape(-1, 7)
 
 
-@pytest.mark.parametrize("name", ["Cornell Smoke", "Easy Cornell Box", "Easy Scene", "Light Demonstration"])
+@pytest.mark.parametrize("name", ["Cornell Smoke", "Easy Cornell Box", "Easy Scene", "Light Demonstration", "Two Sphere"])
 def test_rays_at_rectangle_borders(worlds, name):
-    """The wave walk takes an untransformed rectangle's shape test for its box test (the box is the rectangle,
-    0.002 thick); the per-lane walk tests every box. On borders, corners, one ulp beside them and along the axes
+    """The wave walk takes an untransformed rectangle's or sphere's shape test for its box test (a rectangle's box
+    is the rectangle, 0.002 thick, a sphere's touches it in six points); the per-lane walk tests every box. On borders, corners, one ulp beside them and along the axes
     the two walks -- same arithmetic otherwise -- must give the same answers (a ray lying IN a rectangle's plane
     meets it at t = 0 * inf = NaN, which passes every comparison of the shape test: there the box test decides and
     the wave walk still runs it). Against the checker the same rays
@@ -180,7 +205,7 @@ def test_rays_at_rectangle_borders(worlds, name):
     info, rt, ow = worlds(name)
     rays = rectangle_border_rays(info, per_rect=3000, seed=77)
     if len(rays) == 0:
-        pytest.skip("no untransformed rectangle in this scene")
+        pytest.skip("no untransformed rectangle or sphere in this scene")
     og, tg, ng, pg, fg = rt.world.trace_rays(rays, seed=9)
     rt.world.set_option("traversal", 1)  # per-lane tree walk
     try:
