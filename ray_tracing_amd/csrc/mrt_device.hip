@@ -990,6 +990,15 @@ __device__ __forceinline__ void medium_leaf_wave(RP r, int obj, int flags, bool 
     const double t_min = (double)0.001f;
     bool ok = pass;
     double b1 = 0.0, b2 = 0.0, ray_length = 0.0;
+    {
+        // everything the visit reads of the record -- transform, boundary parameters, density -- requested together
+        // (the node's box is done with); read where it is used it is three round trips, one behind the other
+        auto p = &r->p[0];
+        asm volatile("" ::"s"(r->to_object.r[0][0]), "s"(r->to_object.r[0][1]), "s"(r->to_object.r[0][2]), "s"(r->to_object.r[0][3]),
+                     "s"(r->to_object.r[1][0]), "s"(r->to_object.r[1][1]), "s"(r->to_object.r[1][2]), "s"(r->to_object.r[1][3]),
+                     "s"(r->to_object.r[2][0]), "s"(r->to_object.r[2][1]), "s"(r->to_object.r[2][2]), "s"(r->to_object.r[2][3]),
+                     "s"(p[0]), "s"(p[1]), "s"(p[2]), "s"(p[3]), "s"(p[4]), "s"(p[5]), "s"(p[9]));
+    }
     if (pass) {
         RayD sr = ray;
         D3 inv = inv_world;

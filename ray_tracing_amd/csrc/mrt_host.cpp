@@ -845,11 +845,9 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
                 if (r.identity) r.flags |= NODE_IDENTITY;
                 if (r.translation) r.flags |= NODE_TRANSLATION;
                 r.flags |= (r.kind2 & 0xFF) << NODE_KIND2_SHIFT;
-#ifndef MRT_EXP_NO_IMPLIED
                 if (ob.identity && (sh->kind == MRT_SHAPE_XY_RECT || sh->kind == MRT_SHAPE_XZ_RECT || sh->kind == MRT_SHAPE_YZ_RECT ||
                                     sh->kind == MRT_SHAPE_SPHERE))
                     r.flags |= NODE_BOX_IMPLIED;
-#endif
             }
         }
         build_candidate_tree(&s);
