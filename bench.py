@@ -339,8 +339,8 @@ def main():
             roof = {
                 # What limits the kernel is vector-ALU issue under divergence (see the counter figures below),
                 # not HBM: path state stays in registers between the segments of a launch. `achieved` / `frac`
-                # keep the survey's ALGORITHMIC-bytes accounting (220 B per segment + 24 B per path, the traffic
-                # of a queue-based wavefront tracer) over the kernel's HIP-event time; `measured_hbm_frac` is
+                # keep the ALGORITHMIC-bytes accounting (220 B per segment + 24 B per path, the traffic of a
+                # queue-based wavefront tracer that writes rays and hits to memory between its stages) over the kernel's HIP-event time; `measured_hbm_frac` is
                 # what the kernel really moves.
                 "bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "frac_is": "algorithmic bytes / kernel time / HBM peak",
