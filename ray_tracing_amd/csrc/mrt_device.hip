@@ -622,6 +622,12 @@ struct OctCursor {
     uint32_t leaf_exp;  // size exponent of the node it returned
     bool valid;
 };
+// One node, by a load that names the global address space (a node array whose address went through a register
+// pin has lost that knowledge, and a generic-space load counts against both memory counters).
+__device__ __forceinline__ DOctNode oct_node_at(const DOctNode* nodes, uint32_t i) {
+    const uint64_t raw = ((const __attribute__((address_space(1))) uint64_t*)nodes)[i];
+    return DOctNode{(uint32_t)raw, (int32_t)(raw >> 32)};
+}
 __device__ __forceinline__ DOctNode oct_chunk_near(const DOctNode* nodes, uint32_t root, uint32_t world_log2, OctCursor& c,
                                                    int32_t x, int32_t y, int32_t z) {
     DOctNode n;
@@ -633,17 +639,17 @@ __device__ __forceinline__ DOctNode oct_chunk_near(const DOctNode* nodes, uint32
         if (s <= world_log2) {
             const uint32_t cs = s - 1;
             const uint32_t ci = ((((uint32_t)x >> cs) & 1u) << 2) | ((((uint32_t)y >> cs) & 1u) << 1) | (((uint32_t)z >> cs) & 1u);
-            n = nodes[c.anc[s * c.stride] + ci];
+            n = oct_node_at(nodes, c.anc[s * c.stride] + ci);
             from_root = false;
         }
     }
-    if (from_root) n = nodes[root];
+    if (from_root) n = oct_node_at(nodes, root);
     while ((n.kind_size & 0xFF) == MRT_OCT_PARENT) {
         const uint32_t s = n.kind_size >> 8;
         c.anc[s * c.stride] = (uint32_t)n.link;
         const uint32_t cs = s - 1;
         const uint32_t ci = ((((uint32_t)x >> cs) & 1u) << 2) | ((((uint32_t)y >> cs) & 1u) << 1) | (((uint32_t)z >> cs) & 1u);
-        n = nodes[(uint32_t)n.link + ci];
+        n = oct_node_at(nodes, (uint32_t)n.link + ci);
     }
     c.x = x, c.y = y, c.z = z;
     c.leaf_exp = n.kind_size >> 8;
@@ -736,6 +742,10 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
                                   int32_t bz, D3 origin, D3 d, int initial_normal, const Rng& g, uint32_t& entry, D3& hit_pos,
                                   int& code, int& voxel, OctCursor& cursor) {
     const uint32_t ws = 1u << oc.world_log2;
+    // The node array's address is a field of the scene view in constant memory, which the compiler would rather
+    // read again at every lookup than keep: a scalar round trip in front of each step's node load. As an opaque
+    // value it stays in registers for the walk.
+    asm volatile("" : "+s"(nodes));
     auto in_range = [&](int32_t x, int32_t y, int32_t z) {  // 0 <= v < ws, negative values wrap above ws
         return (uint32_t)x < ws && (uint32_t)y < ws && (uint32_t)z < ws;
     };
@@ -774,8 +784,10 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
         // The reference has six copies of this step (axis x sign, ray_trace.rs:222-470); here the axis
         // is a value, so the lanes of a wave take one path and issue one lookup together. The
         // smallest t picks the axis, ties fall to z (ray_trace.rs:398).
-        const bool ax0 = tx < ty && tx < tz, ax1 = !ax0 && ty < tx && ty < tz, ax2 = !ax0 && !ax1;
-        const double tm = ax2 ? tz : vmin_f64(tx, ty);  // x or y win only as the strict minimum
+        // (bitwise, not short-circuit: the compiler turns `&&` between comparisons into branches here)
+        const bool ax0 = (tx < ty) & (tx < tz), ax1 = !ax0 & (ty < tx) & (ty < tz), ax2 = !ax0 & !ax1;
+        const double txy = vmin_f64(tx, ty);
+        const double tm = ax2 ? tz : txy;  // x or y win only as the strict minimum
         const int32_t ba = ax0 ? bx : (ax1 ? by : bz);
         cur.x += tm * d.x, cur.y += tm * d.y, cur.z += tm * d.z;
         const int32_t cx = f64_as_i32(cur.x), cy = f64_as_i32(cur.y), cz = f64_as_i32(cur.z);
