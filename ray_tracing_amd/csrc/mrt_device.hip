@@ -224,6 +224,17 @@ __device__ __forceinline__ double rcp_fast(double x) {
     // inf - inf in the update)
     return r1 == r1 ? r1 : r;
 }
+// a / d, correctly rounded, from inv = 1 / d rounded to nearest (Markstein's division): the product is within
+// two units of the last place of a / d, one correction by the exact residual makes it faithful, and a second one
+// on a faithful quotient gives the correctly rounded one -- seven instructions for the thirty of a division.
+// Holds for d a normal number of moderate size whose significand is not all ones, and a zero or far from the
+// ends of the exponent range; NaN stays NaN.
+__device__ __forceinline__ double div_by_reciprocal(double a, double d, double inv) {
+#pragma clang fp contract(off)
+    const double q0 = a * inv;
+    const double q1 = fma(fma(-d, q0, a), inv, q0);
+    return fma(fma(-d, q1, a), inv, q1);
+}
 // 1/sqrt(x) from v_rsq_f64 plus two Newton steps, for x > 0 finite.
 __device__ __forceinline__ double rsqrt_fast(double x) {
     double y = __builtin_amdgcn_rsq(x);
@@ -1518,8 +1529,9 @@ struct Surface {
 __device__ __forceinline__ void sphere_uv(D3 p, double& u, double& v) {  // sphere.rs:111-115
     double theta = acos(-p.y);
     double phi = atan2(-p.z, p.x) + M_PI;
-    u = phi / (2.0 * M_PI);
-    v = theta / M_PI;
+    // (the two quotients as the division gives them, by the constants' reciprocals; theta and phi are 0 .. 2 pi)
+    u = div_by_reciprocal(phi, 2.0 * M_PI, 1.0 / (2.0 * M_PI));
+    v = div_by_reciprocal(theta, M_PI, 1.0 / M_PI);
 }
 template <int AXIS>
 __device__ __forceinline__ void rect_uv(double a0, double a1, double b0, double b1, const Surface& s, double& u,
@@ -2058,12 +2070,10 @@ __device__ F3 background_color(SceneRef sv, const RayD& ray) {
 }
 
 // ============================================================== camera (camera.rs:88-106, ray_tracer.rs:444-447)
-// a / d, correctly rounded, from inv = 1 / d rounded to nearest: the product, then one correction by the exact
-// residual (three instructions for the sixteen of a division). inv = NaN (d is not a normal number): the division.
+// a / d by the reciprocal the host gives (div_by_reciprocal); inv = NaN (d is out of its range): the division.
 __device__ __forceinline__ double div_by(double a, double d, double inv) {
     if (!(inv == inv)) return a / d;  // (the same for every lane)
-    const double q = a * inv;
-    return fma(fma(-d, q, a), inv, q);
+    return div_by_reciprocal(a, d, inv);
 }
 __host__ __device__ inline double reciprocal_for_div_by(double d) {
     return (d >= 1.0 && d <= 1e15) ? 1.0 / d : __builtin_nan("");
