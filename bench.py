@@ -19,6 +19,7 @@ rank 0's JSON line through. Started under torch.distributed.run it is one of the
 from __future__ import annotations
 
 import argparse
+import datetime
 import glob
 import json
 import os
@@ -60,23 +61,58 @@ def parse_args(argv=None):
 
 def launch_ranks(args) -> int:
     """Starts args.gpus fresh rank processes of this script (nothing in this process has touched
-    torch or the GPU) and passes rank 0's output through. Returns the worst exit code."""
+    torch or the GPU), watches ALL of them and passes rank 0's output through. When any rank ends with
+    an error the others are ended within seconds (they would otherwise sit in the rendezvous or in a
+    collective until its timeout) and the error code is returned. Every rank's stderr is kept in
+    gpurun_out/rank<k>.err."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    log_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(log_dir, exist_ok=True)
+    procs, errs = [], []
+    out0 = open(os.path.join(log_dir, "rank0.out"), "w+")
     for rank in range(args.gpus):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        err = open(os.path.join(log_dir, f"rank{rank}.err"), "w+")
+        errs.append(err)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+                                      stdout=out0 if rank == 0 else subprocess.DEVNULL, stderr=err))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for rank, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = rank
+                break
+        else:
+            time.sleep(0.1)
+    if failed is None:
+        failed = next((rank for rank, p in enumerate(procs) if p.returncode != 0), None)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        errs[failed].seek(0)
+        sys.stderr.write(f"bench.py: rank {failed} ended with code {procs[failed].returncode}; the other ranks were stopped. "
+                         f"Its stderr (gpurun_out/rank{failed}.err) ends:\n{errs[failed].read()[-2000:]}\n")
+    out0.seek(0)
+    sys.stdout.write(out0.read())
     sys.stdout.flush()
-    return max(abs(c) for c in codes)
+    for f in errs + [out0]:
+        f.close()
+    if failed is not None:
+        return abs(procs[failed].returncode) or 1
+    return 0
 
 
 def cpu_baseline(info, width, height, spp, threads, label):
@@ -163,8 +199,7 @@ def committed_profile(workload_key):
 def scene_name(name):
     """Display name of a scenario given either the display name or its key form (`random_scene`, `voxel_city`)."""
     from ray_tracing_amd import scenarios
-    names = list(scenarios.SCENARIOS) + ["Light Demonstration", "Easy Scene", "Voxel City", "Fast Oct Tree Apartment Building",
-                                         "Fast Oct Tree Sinnoh"]
+    names = list(scenarios.SCENARIOS) + list(scenarios.ASSET_SCENARIOS)
     key = name.lower().replace(",", "").replace(" ", "_")
     for n in names:
         if n.lower().replace(",", "").replace(" ", "_") == key:
@@ -174,10 +209,8 @@ def scene_name(name):
 
 def build_scene(name):
     from ray_tracing_amd import scenarios
-    if name == "Cornell Smoke":
-        return scenarios.cornell_smoke()
-    from tests.helpers import scene_by_name   # data fixtures (decoded .vox, earthmap) live under tests/golden
-    return scene_by_name(name)
+    # the decoded asset files (.vox models, tile map, earthmap) are kept as data under tests/golden
+    return scenarios.build_with_assets(name, os.path.join(ROOT, "tests", "golden"))
 
 
 def post_leg(rt, accum, W, H, spp, repeats=5):
@@ -232,11 +265,15 @@ def main():
         if local_rank >= torch.cuda.device_count():
             raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node")
         torch.cuda.set_device(local_rank)
+    if os.environ.get("MRT_BENCH_FAIL_RANK") == str(rank):    # rehearsal of a rank that dies before the rendezvous
+        raise SystemExit(f"rank {rank}: failure injected by MRT_BENCH_FAIL_RANK")
     if world_size > 1:
+        # a rank that never arrives must not hold the others for torch's default half hour
+        limit = datetime.timedelta(seconds=float(os.environ.get("MRT_BENCH_RENDEZVOUS_S", "300")))
         if args.backend == "nccl" and use_gpu:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=limit)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=limit)
 
     args.scene = scene_name(args.scene)
     W, H = args.width, args.height
@@ -269,9 +306,26 @@ def main():
         totals["kernel_ms"] += st.kernel_ms
         totals["launches"] += st.launches
 
+    ar_events, ar_host_ms = [], [0.0]
+
+    def all_reduce():
+        """The one collective of a step, timed on its own: device events around it on the stream the render ran on
+        (the collective's own stream is joined to it), the host clock for gloo. The time includes the wait for the
+        slowest rank to arrive."""
+        if use_gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(accum)
+            e1.record()
+            ar_events.append((e0, e1))
+        else:
+            t = time.perf_counter()
+            dist.all_reduce(accum)
+            ar_host_ms[0] += (time.perf_counter() - t) * 1e3
+
     def step():
         accum.zero_()
-        render_sharded(render, lambda: dist.all_reduce(accum), total_spp, rank, world_size)
+        render_sharded(render, all_reduce, total_spp, rank, world_size)
 
     def sync():
         if world_size > 1:
@@ -284,20 +338,40 @@ def main():
     for k in totals:
         totals[k] = 0 if k != "kernel_ms" else 0.0
     sync()
+    ar_events.clear()
+    ar_host_ms[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
+    collective = None
     if world_size > 1:
+        own_elapsed = elapsed
+        ar_ms = ar_host_ms[0] + sum(e0.elapsed_time(e1) for e0, e1 in ar_events)
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         c = torch.tensor([totals["paths"], totals["rays"], totals["lq"]], dtype=torch.float64, device=device)
         dist.all_reduce(c)
         all_paths, all_rays, all_lq = (float(x) for x in c.tolist())
+        # what every rank did, as the ranks themselves saw it: proof that the collective joined world_size ranks
+        mine = torch.tensor([float(rank), float(totals["paths"]), own_elapsed, ar_ms, float(my_spp)], dtype=torch.float64,
+                            device=device)
+        gathered = [torch.zeros_like(mine) for _ in range(world_size)]
+        dist.all_gather(gathered, mine)
+        rows = sorted((g.tolist() for g in gathered), key=lambda r: r[0])
+        collective = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                      "ranks_seen": [int(r[0]) for r in rows],
+                      "bytes": accum.numel() * accum.element_size(), "calls_per_step": 1,
+                      "allreduce_ms": ar_ms / max(1, args.steps),
+                      "allreduce_ms_per_rank": [r[3] / max(1, args.steps) for r in rows],
+                      "allreduce_ms_is": "per step, timed around the call on each rank: transfer + wait for the slowest rank",
+                      "spp_per_rank": [int(r[4]) for r in rows]}
+        per_rank_mpaths = [r[1] / r[2] / 1e6 if r[2] > 0 else 0.0 for r in rows]
     else:
         all_paths, all_rays, all_lq = float(totals["paths"]), float(totals["rays"]), float(totals["lq"])
+        per_rank_mpaths = [all_paths / elapsed / 1e6]
 
     if rank == 0:
         mean = accum.double().mean().item() / max(1, total_spp)
@@ -330,7 +404,10 @@ def main():
             "light_queries_per_s_M": all_lq / elapsed / 1e6,
             "segments_per_path": all_rays / all_paths if all_paths else 0.0,
             "mean_radiance": mean,
+            "per_rank_mpaths": per_rank_mpaths,
         }
+        if collective:
+            out["collective"] = collective
         if args.dry:
             out["dry"] = True
             out["config"]["workload"] = "dry run: no rendering, rank plumbing and all-reduce only"

@@ -494,3 +494,24 @@ def build(name: str, earthmap: Optional[np.ndarray] = None) -> WorldInfo:
             raise ValueError(f"{name!r} needs the decoded earthmap image (scenarios.load_earthmap_fixture)")
         return light_demo(earthmap) if name == "Light Demonstration" else easy_scene(earthmap)
     return SCENARIOS[name]()
+
+
+ASSET_SCENARIOS = ("Light Demonstration", "Easy Scene", "Voxel City", "Fast Oct Tree Apartment Building",
+                   "Fast Oct Tree Sinnoh")
+
+
+def build_with_assets(name: str, assets_dir: str) -> WorldInfo:
+    """Scenario by its display name, for a host that holds the reference's asset files as decoded data:
+    `assets_dir` contains `earthmap_rgb8.npz` (assets/earthmap.jpg), `skyscraper0_vox.npz`,
+    `apartment_building_vox.npz` (voxel_assets/**.vox) and `sinnoh_map.npz` (voxel_assets/sinnoh/twinleaf.yml
+    with its models). Scenarios without assets ignore the directory."""
+    import os
+    if name == "Voxel City":
+        return voxel_city(load_vox_fixture(os.path.join(assets_dir, "skyscraper0_vox.npz")))
+    if name == "Fast Oct Tree Apartment Building":
+        return apartment_building(load_vox_fixture(os.path.join(assets_dir, "apartment_building_vox.npz")))
+    if name == "Fast Oct Tree Sinnoh":
+        return sinnoh(*load_map_fixture(os.path.join(assets_dir, "sinnoh_map.npz")))
+    if name in ("Light Demonstration", "Easy Scene"):
+        return build(name, load_earthmap_fixture(os.path.join(assets_dir, "earthmap_rgb8.npz")))
+    return build(name)

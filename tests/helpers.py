@@ -20,15 +20,9 @@ def golden_key(name: str) -> str:
 
 
 def scene_by_name(name: str) -> WorldInfo:
-    if name == "Voxel City":
-        return scenarios.voxel_city(scenarios.load_vox_fixture(os.path.join(GOLDEN_DIR, "skyscraper0_vox.npz")))
-    if name == "Fast Oct Tree Apartment Building":
-        return scenarios.apartment_building(scenarios.load_vox_fixture(os.path.join(GOLDEN_DIR, "apartment_building_vox.npz")))
-    if name == "Fast Oct Tree Sinnoh":
-        return scenarios.sinnoh(*scenarios.load_map_fixture(os.path.join(GOLDEN_DIR, "sinnoh_map.npz")))
     if name in ("Light Demonstration", "Easy Scene"):
         return scenarios.build(name, earthmap())
-    return scenarios.build(name)
+    return scenarios.build_with_assets(name, GOLDEN_DIR)
 
 
 @functools.lru_cache(maxsize=None)

@@ -88,11 +88,17 @@ def test_bench_starts_its_own_ranks_weak_and_strong():
     weak = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", "--steps", "2", "--warmup", "1", "--width", "32",
                       "--height", "16", "--spp", "4")
     assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["dry"] is True
+    # what the collective saw, reported by the ranks themselves (n_gpus alone is copied from the command line)
+    col = weak["collective"]
+    assert col["world_size"] == 2 and col["ranks_seen"] == [0, 1] and col["backend"] == "gloo"
+    assert col["bytes"] == 32 * 16 * 3 * 4 and col["allreduce_ms"] > 0 and col["spp_per_rank"] == [4, 4]
+    assert len(weak["per_rank_mpaths"]) == 2 and all(v > 0 for v in weak["per_rank_mpaths"])
     assert weak["mean_radiance"] == 1.0
     assert weak["value"] > 0 and abs(weak["value"] * weak["ms_per_step"] * 1e3 - 32 * 16 * 4 * 2) < 1e-3 * 32 * 16 * 8
     strong = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", "--strong", "--steps", "1", "--warmup", "0",
                         "--width", "32", "--height", "16", "--spp", "5")
     assert strong["n_gpus"] == 2 and strong["scaling"] == "strong" and strong["mean_radiance"] == 1.0
+    assert strong["collective"]["spp_per_rank"] == [3, 2]
     assert abs(strong["value"] * strong["ms_per_step"] * 1e3 - 32 * 16 * 5) < 1e-3 * 32 * 16 * 5
 
 
@@ -104,3 +110,24 @@ def test_bench_refuses_a_launcher_with_another_world_size():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry", "--backend", "gloo"],
                        env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_bench_ends_quickly_when_one_rank_dies():
+    """A rank that ends before the rendezvous (no such GPU, a scene error, a failed RCCL start) must not leave the
+    others waiting in `init_process_group` until its timeout: the launcher stops them and returns the error."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MRT_BENCH_FAIL_RANK"] = "1"
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry",
+                        "--steps", "1", "--warmup", "0", "--width", "32", "--height", "16", "--spp", "4"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0
+    assert time.monotonic() - t0 < 20.0
+    assert "rank 1" in p.stderr and "MRT_BENCH_FAIL_RANK" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]     # no result line from a failed run
+    with open(os.path.join(root, "gpurun_out", "rank1.err")) as f:
+        assert "MRT_BENCH_FAIL_RANK" in f.read()
