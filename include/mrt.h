@@ -335,14 +335,19 @@ int mrt_render_accumulate(mrt_scene* scene, float* accum_rgb, uint32_t width, ui
  * calls (handles that share a device share its image). The strip of `accum_rgb`
  * (HOST memory) is uploaded once, the per-device images are summed on the
  * devices with one ncclAllReduce per device (RCCL, bound with dlopen at first
- * use; a host-side sum of the downloaded strips replaces it when the library
- * cannot be loaded), and the strip is downloaded once: the result is the
- * one-handle result up to the order of the f32 additions. With the environment
- * variable MRT_MULTI_FORCE_RCCL set, the collective also runs when all handles
- * share one device (a world of one), and a failure of it is an error instead of
- * a fall-back. `stats`: sums of the counters, the longest kernel time, the wall
+ * use), and the strip is downloaded once: the result is the one-handle result
+ * up to the order of the f32 additions. A host-side sum of the downloaded
+ * strips replaces the collective ONLY when RCCL is not there (the library
+ * cannot be loaded or its communicators cannot be made), i.e. before any image
+ * has been touched; a failure after the collectives were started leaves partly
+ * reduced images and is MRT_ERR_DEVICE. With the environment variable
+ * MRT_MULTI_FORCE_RCCL set, the collective also runs when all handles share one
+ * device (a world of one), and a missing RCCL is an error instead of a
+ * fall-back. `stats`: sums of the counters, the longest kernel time, the wall
  * time of the call. Multi-process hosts split the samples the same way and
- * all-reduce the buffers themselves (one rank per GPU). */
+ * all-reduce the buffers themselves (one rank per GPU). The per-device tables
+ * of this call, of the no-allocation entry point and of mrt_bloom* hold device
+ * ordinals 0..63. */
 int mrt_render_accumulate_multi(mrt_scene* const* scenes, uint32_t n_scenes, float* accum_rgb,
                                 uint32_t width, uint32_t height, uint32_t x0, uint32_t strip_w,
                                 uint32_t spp, uint64_t seed, uint64_t first_sample_index,
@@ -360,13 +365,19 @@ int mrt_render_accumulate_device(mrt_scene* scene, float* accum_rgb_device, uint
                                  uint64_t seed, uint64_t first_sample_index, void* stream,
                                  mrt_stats* stats);
 
-/* mrt_render_accumulate_device for callers that cannot allocate (code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc). It has no counterpart in the reference.
+/* mrt_render_accumulate_device for callers that cannot ALLOCATE while they render (serving loops
+ * that add a sample per frame under a fixed memory budget, harnesses that forbid hipMalloc after
+ * start-up, hosts that have handed all free device memory to another library). It has no
+ * counterpart in the reference.
  * Same arguments, same samples and the same image (up to the order of the f32 additions), but the
  * call allocates nothing on the device or the host: the path pool, the counters and the per-wave
  * work ranges live in a device array that is part of the library's code object
  * (MRT_NOALLOC_SCRATCH_BYTES bytes on every GPU the library runs on, held until the process
  * ends), and the events and the pinned counter copy were created with the scene.
+ * It is NOT for code under HIP stream capture: like every render entry point it is a host-driven
+ * loop -- it queries the buffer's pointer attributes, synchronises `stream` after every kernel
+ * launch, reads the counters and the event times back and decides the next launch on the host --
+ * and all of that is illegal while a stream is being captured.
  * Limits: the pool is MRT_NOALLOC_POOL_SLOTS path slots whatever "pool_slots" says, and the drain
  * phase does not pack the pool ("compaction" is ignored); neither grows with the image, so the
  * sizes that are rejected (MRT_ERR_INVALID_ARGUMENT) are those of every render entry point:

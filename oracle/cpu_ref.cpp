@@ -1653,6 +1653,32 @@ int oracle_sample_radiance(void* scene, uint32_t width, uint32_t height, const i
     return MRT_OK;
 }
 
+// Probe of LambertianPDF::generate (pdf.rs:234-282) on n given surface points: point i has normal
+// normals[i], the incoming ray's time in_times[i], and draws from the stream of pixel index i, sample 0,
+// segment `seg`. Outputs: the sampled direction, the mixture "pdf" value, the branch drawn (0 cosine,
+// 1 light list, 2 sky) and whether generate returned Some. For an independent restatement to be checked
+// against (tests/test_pdf_restatement.py).
+int oracle_lambertian_generate(void* scene, const double* points, const double* normals, const double* in_times, size_t n,
+                               uint64_t seed, uint32_t seg, double* dir_out, double* value_out, int32_t* choice_out,
+                               int32_t* some_out) {
+    auto* s = static_cast<Scene*>(scene);
+    if (!s || !points || !normals || !in_times || !dir_out || !value_out || !choice_out || !some_out) return MRT_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < n; ++i) {
+        g_rng = RngCtx{};
+        g_rng.key = path_key(seed, (uint64_t)i, 0);
+        g_rng.seg = seg;
+        const V3 p{points[3 * i], points[3 * i + 1], points[3 * i + 2]};
+        const V3 nrm{normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]};
+        const Ray incoming{p, V3{0.0, 0.0, 1.0}, in_times[i]};  // generate reads only the time of the incoming ray
+        choice_out[i] = (int32_t)rand_u32(0, 3, MRT_DIM_PDF_CHOICE);
+        auto v = lambertian_pdf_generate(nrm, incoming, p, s->world);
+        some_out[i] = v ? 1 : 0;
+        dir_out[3 * i] = v ? v->direction.x : 0.0, dir_out[3 * i + 1] = v ? v->direction.y : 0.0, dir_out[3 * i + 2] = v ? v->direction.z : 0.0;
+        value_out[i] = v ? v->value : 0.0;
+    }
+    return MRT_OK;
+}
+
 uint64_t oracle_rng_u64(uint64_t seed, uint64_t pixel, uint64_t sample, uint32_t seg, uint32_t dim) {
     uint64_t key = path_key(seed, pixel, sample);
     return mix64(key + 0x9E3779B97F4A7C15ULL * ((((uint64_t)seg << 16) | dim) + 1));

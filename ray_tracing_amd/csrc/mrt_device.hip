@@ -118,6 +118,7 @@ struct Counters {
     unsigned int live;
     unsigned int compacted;
     unsigned long long held;  // work items claimed by waves but not started when the launch ended
+    unsigned long long paths;  // paths that ended (their radiance added to the image), counted where they end
     unsigned long long stamps[ST_COUNT];  // diagnostic build only
     unsigned long long stamp_lanes[ST_COUNT];
     unsigned long long stamp_counts[12];
@@ -389,7 +390,8 @@ __device__ D3 wave_rand_unit_vec(bool want, uint64_t rng_base, uint32_t dim_base
         D3 v = 2.0 * (rv - D3{0.5, 0.5, 0.5});
         const bool ok = q < n && attempt < MRT_MAX_REJECT && dot(v, v) < 1.0;
         const unsigned long long accepted = __ballot(ok);
-        const uint32_t mine = (uint32_t)(accepted >> (rank << log_a)) & ((1u << (1u << log_a)) - 1u);
+        // (a lane without a request can have rank == n, i.e. a shift by 64: masked, its value is not used)
+        const uint32_t mine = (uint32_t)(accepted >> ((rank << log_a) & 63u)) & ((1u << (1u << log_a)) - 1u);
         const bool found = want && mine != 0;
         const int sel = (int)((found ? (rank << log_a) + (uint32_t)__builtin_ctz(mine) : lane) << 2);
         D3 got;
@@ -986,7 +988,7 @@ __device__ __forceinline__ bool object_hit(SceneRef sv, OP ob, const RayD& ray, 
                                            double t_max, const Rng& g, uint32_t medium_dim, uint32_t& oct_entry, double& t,
                                            int& sub, D3& pos) {
     return leaf_hit<FEAT>(sv, ob->kind, ob->gkind, ob->octree, &ob->p[0], ob->p[9], ob->identity != 0, &ob->to_object, ray,
-                          inv_world, t_min, t_max, g, medium_dim, oct_entry, t, sub, pos);
+                          inv_world, t_min, t_max, g, medium_dim, oct_entry, t, sub, pos, ob->translation != 0);
 }
 // Leaf test of the wave-synchronous walk from a self-contained node record (scalar operands). `kind` and `flags`
 // are the record's, which the walk holds already.
@@ -1566,7 +1568,11 @@ __device__ void surface_uv(OP sh, const Surface& s, double& u, double& v) {
 }
 template <int FEAT, class OP>
 __device__ void surface_at(OP ob, const RayD& ray, double t, int sub, D3 oct_pos, Surface& s) {
-    RayD sr = ob->identity ? ray : xform_ray(&ob->to_object, false, ray);
+    // (the object-space ray the leaf test used: an untransformed object sees the world ray, a translated one the
+    // world direction from the moved origin, see leaf_hit -- t and the hit point then come from ONE direction)
+    RayD sr = ray;
+    if (ob->translation) sr.o = {ray.o.x + ob->to_object.r[0][3], ray.o.y + ob->to_object.r[1][3], ray.o.z + ob->to_object.r[2][3]};
+    else if (!ob->identity) sr = xform_ray(&ob->to_object, false, ray);
     OP sh = ob;
     auto p = sh->p;
     s.pos_obj = ray_at(sr, t);
@@ -2416,6 +2422,7 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
         }
     }
     uint32_t rays = 0, light_queries = 0;
+    uint32_t ended = 0;  // paths of this wave that ended in this launch (wave-uniform: a scalar register)
     // this wave's share of the work range (wave-uniform)
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(slot >> 6);
     unsigned long long chunk_next = wave_chunks[2 * (size_t)wave_id];
@@ -2507,9 +2514,10 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
         F3 radiance;
         bool cont = path_segment<WAVE, FEAT>(sv, ray, thr, g, live, radiance, rays, light_queries, st, cand_bits, perlin_lds);
         REGION_BEGIN(acc);
+        if (live && cont && seg >= 49) cont = false;  // depth 50 -> 0 returns BLACK (ray_tracer.rs:166-172, :451)
+        ended += (uint32_t)__popcll(__ballot(live && !cont));
         if (live) {
             seg++;
-            if (cont && seg >= 50) cont = false;  // depth 50 -> 0 returns BLACK (ray_tracer.rs:166-172, :451)
             if (!cont) {
                 // ParallelImagePart::add_xy, parallel_image.rs:328-331
                 float* px = rp.accum + (size_t)pixel * 3;
@@ -2550,6 +2558,7 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
         if (live) atomicAdd(&ctr->live, live);
         if (rays) atomicAdd(&ctr->rays, (unsigned long long)rays);
         if (light_queries) atomicAdd(&ctr->light_queries, (unsigned long long)light_queries);
+        if (ended) atomicAdd(&ctr->paths, (unsigned long long)ended);
     }
 }
 
@@ -2655,8 +2664,10 @@ __global__ void __launch_bounds__(BLOCK) k_single_bounce(const SceneView* svp, R
         if (color.g != 0.f) atomicAdd(px + 1, color.g);
         if (color.b != 0.f) atomicAdd(px + 2, color.b);
     }
+    const uint32_t ended = (uint32_t)__popcll(__ballot(live));
     rays = wave_sum(rays);
     if (lane_id() == 0 && rays) atomicAdd(&ctr->rays, (unsigned long long)rays);
+    if (lane_id() == 0 && ended) atomicAdd(&ctr->paths, (unsigned long long)ended);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_init_pool(Pool pool, uint32_t n, unsigned long long* wave_chunks) {
@@ -3144,8 +3155,10 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
         float ms = 0.f, total = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ek0, ek1));
         HIP_TRY(hipEventElapsedTime(&total, ev_begin, ev_end));
+        if (done.paths != rp.n_work)
+            return set_error(MRT_ERR_DEVICE, "the kernels ended " + std::to_string(done.paths) + " paths of " + std::to_string(rp.n_work));
         if (stats) {
-            stats->paths = rp.n_work;
+            stats->paths = done.paths;
             stats->rays = done.rays;
             stats->launches = n_launch;
             stats->kernel_ms = ms;
@@ -3245,8 +3258,12 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
                          (double)host.stamp_lanes[i] / (double)std::max(1ull, host.stamps[i]));
     }
 #endif
+    // every pixel-sample handed out must have ended on the device: a kernel that dropped work is an error,
+    // not a fast render
+    if (host.paths != rp.n_work)
+        return set_error(MRT_ERR_DEVICE, "the kernels ended " + std::to_string(host.paths) + " paths of " + std::to_string(rp.n_work));
     if (stats) {
-        stats->paths = rp.n_work;
+        stats->paths = host.paths;
         stats->rays = host.rays;
         stats->light_queries = host.light_queries;
         stats->launches = launches;
@@ -3292,13 +3309,21 @@ Rccl& rccl() {
 std::mutex g_multi_mu;  // mrt_render_accumulate_multi calls take turns (resident images, communicators)
 
 // In-place sum of one f32 image per device over all devices: one ncclAllReduce per device inside one
-// group call (RCCL over xGMI between GPUs; a copy when there is one device). Returns false with
-// `why` set when RCCL is unavailable or fails; the caller then sums on the host.
-bool all_reduce_images(const std::vector<int>& devices, const std::vector<float*>& images, size_t n_float, std::string& why) {
+// group call (RCCL over xGMI between GPUs; a copy when there is one device).
+//   JOIN_DONE         the images hold the sum;
+//   JOIN_UNAVAILABLE  RCCL could not be loaded or its communicators could not be made: NO image has been
+//                     touched, the caller may sum on the host;
+//   JOIN_FAILED       a call failed after the collectives were started: the images may be partly reduced,
+//                     nothing can be built on them.
+// MRT_MULTI_INJECT_FAILURE=load|collective makes the function answer as if the library were missing / as
+// if the collective had failed after it was enqueued (for tests of the two ways out).
+enum JoinResult { JOIN_DONE, JOIN_UNAVAILABLE, JOIN_FAILED };
+JoinResult all_reduce_images(const std::vector<int>& devices, const std::vector<float*>& images, size_t n_float, std::string& why) {
+    const char* inject = std::getenv("MRT_MULTI_INJECT_FAILURE");
     Rccl& r = rccl();
-    if (!r.ok) {
+    if (!r.ok || (inject && std::strcmp(inject, "load") == 0)) {
         why = "librccl could not be loaded";
-        return false;
+        return JOIN_UNAVAILABLE;
     }
     auto it = r.comms.find(devices);
     if (it == r.comms.end()) {
@@ -3306,11 +3331,15 @@ bool all_reduce_images(const std::vector<int>& devices, const std::vector<float*
         const ncclResult_t rc = r.comm_init_all(c.data(), (int)devices.size(), devices.data());
         if (rc != ncclSuccess) {
             why = std::string("ncclCommInitAll: ") + r.error_string(rc);
-            return false;
+            return JOIN_UNAVAILABLE;
         }
         it = r.comms.emplace(devices, std::move(c)).first;
     }
     ncclResult_t rc = r.group_start();
+    if (rc != ncclSuccess) {
+        why = std::string("ncclGroupStart: ") + r.error_string(rc);
+        return JOIN_UNAVAILABLE;  // nothing enqueued yet
+    }
     for (size_t g = 0; g < devices.size() && rc == ncclSuccess; ++g) {
         if (hipSetDevice(devices[g]) != hipSuccess) rc = ncclUnhandledCudaError;
         else rc = r.all_reduce(images[g], images[g], n_float, ncclFloat, ncclSum, it->second[g], nullptr);
@@ -3320,11 +3349,12 @@ bool all_reduce_images(const std::vector<int>& devices, const std::vector<float*
     bool synced = true;
     for (size_t g = 0; g < devices.size(); ++g)
         synced = hipSetDevice(devices[g]) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess && synced;
+    if (rc == ncclSuccess && inject && std::strcmp(inject, "collective") == 0) rc = ncclInternalError;
     if (rc != ncclSuccess || !synced) {
         why = rc != ncclSuccess ? std::string("ncclAllReduce: ") + r.error_string(rc) : "synchronisation after the all-reduce failed";
-        return false;
+        return JOIN_FAILED;
     }
-    return true;
+    return JOIN_DONE;
 }
 
 // Body of mrt_render_accumulate_multi (arguments checked by the caller). Each GPU holds ONE resident
@@ -3402,12 +3432,17 @@ int render_multi(mrt_scene* const* scenes, uint32_t n_scenes, float* accum_rgb, 
         if (s.rc != MRT_OK) return set_error(s.rc, s.message);
     // join the per-device images: on the devices when RCCL is there (always for several devices; for one
     // device only when MRT_MULTI_FORCE_RCCL is set, which lets a one-GPU host exercise the collective)
-    const bool want_collective = devices.size() > 1 || std::getenv("MRT_MULTI_FORCE_RCCL") != nullptr;
+    const bool forced = std::getenv("MRT_MULTI_FORCE_RCCL") != nullptr;
+    const bool want_collective = devices.size() > 1 || forced;
     bool reduced = devices.size() == 1;
     std::string why;
     if (want_collective) {
-        reduced = all_reduce_images(devices, images, n_float, why) || devices.size() == 1;
-        if (std::getenv("MRT_MULTI_FORCE_RCCL") != nullptr && !why.empty()) return set_error(MRT_ERR_DEVICE, why);
+        const JoinResult jr = all_reduce_images(devices, images, n_float, why);
+        // a failure after the collectives were enqueued leaves partly reduced images: adding the other devices'
+        // strips on the host would count samples twice. Only "RCCL is not there" falls back to the host sum.
+        if (jr == JOIN_FAILED) return set_error(MRT_ERR_DEVICE, why);
+        if (jr == JOIN_UNAVAILABLE && forced && std::getenv("MRT_MULTI_INJECT_FAILURE") == nullptr) return set_error(MRT_ERR_DEVICE, why);
+        reduced = jr == JOIN_DONE || devices.size() == 1;
     }
     HIP_TRY(hipSetDevice(devices[0]));
     HIP_TRY(hipMemcpy2D(accum_rgb + 3 * (size_t)x0, host_pitch, images[0] + 3 * (size_t)x0, host_pitch, strip_bytes, height,

@@ -718,6 +718,10 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
         }
         r.to_object = ob.to_object, r.to_world = ob.to_world;
         std::memcpy(r.normal_m, ob.normal_m, sizeof(r.normal_m));
+        r.translation = ob.identity ? 0 : 1;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b)
+                if (ob.to_object.r[a][b] != (a == b ? 1.0 : 0.0)) r.translation = 0;
         return r;
     };
     for (const DObject& ob : s.objects) s.obj_recs.push_back(mk_rec(ob));

@@ -167,7 +167,7 @@ struct DObjRec {
     int32_t mat_kind;   // material kind (phase function for media); unused for OCTREE
     int32_t texture;    // texture index of the material
     int32_t tex_solid;  // 1: the texture is a SolidColor and `color` holds its value
-    int32_t pad;
+    int32_t translation;  // the object transform is a pure translation (linear part exactly the identity), not the identity
     float color[3];     // SolidColor value, or the Dielectric colour
     int32_t pad2;
     double fuzz, index_refraction;

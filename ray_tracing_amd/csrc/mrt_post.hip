@@ -158,7 +158,10 @@ struct BloomWork {
     float* level[LEVELS + 1] = {};
 };
 constexpr int MAX_DEVICES = 64;
-BloomWork g_bloom_work[MAX_DEVICES];
+// Never destroyed: the HIP runtime registers its own teardown at the first HIP call, i.e. after this
+// library was loaded, so at process exit it is gone before a static destructor here would run, and
+// hipFree on a torn-down runtime is undefined. The process's end returns the memory.
+BloomWork* const g_bloom_work = new BloomWork[MAX_DEVICES];
 
 inline dim3 grid_for(size_t n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); }
 

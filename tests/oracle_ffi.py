@@ -32,6 +32,7 @@ def load():
     lib.oracle_render_accumulate.argtypes = [vp, vp, u32, u32, u32, u32, u32, u64, u64, u32, C.c_int,
                                              C.POINTER(F.Stats)]
     lib.oracle_sample_radiance.argtypes = [vp, u32, u32, vp, sz, u64, u64, vp]
+    lib.oracle_lambertian_generate.argtypes = [vp, vp, vp, vp, sz, u64, u32, vp, vp, vp, vp]
     lib.oracle_rng_u64.restype = u64
     lib.oracle_rng_u64.argtypes = [u64, u64, u64, u32, u32]
     lib.oracle_to_image.argtypes = [vp, u32, u32, u32, vp]
@@ -96,6 +97,20 @@ class OracleWorld:
                                                first_sample, threads, rng_mode, C.byref(st))
         assert rc == 0
         return accum, st
+
+    def lambertian_generate(self, points, normals, in_times, seed, seg=0):
+        """LambertianPDF::generate at given surface points: (direction n x 3, value n, branch n, some n)."""
+        p = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 3)
+        nr = np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3)
+        tm = np.ascontiguousarray(in_times, dtype=np.float64).reshape(-1)
+        n = len(p)
+        d = np.zeros((n, 3), dtype=np.float64)
+        val = np.zeros(n, dtype=np.float64)
+        choice = np.zeros(n, dtype=np.int32)
+        some = np.zeros(n, dtype=np.int32)
+        assert self.lib.oracle_lambertian_generate(self.handle, p.ctypes.data, nr.ctypes.data, tm.ctypes.data, n, seed, seg,
+                                                   d.ctypes.data, val.ctypes.data, choice.ctypes.data, some.ctypes.data) == 0
+        return d, val, choice, some
 
     def sample_radiance(self, width, height, pixels, seed, sample_index):
         px = np.ascontiguousarray(pixels, dtype=np.int32).reshape(-1, 2)

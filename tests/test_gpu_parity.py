@@ -9,6 +9,7 @@ Tier B: statistical -- RMSE(GPU, CPU independent estimator) <= 1.15 * RMSE(CPU, 
         channel means within 0.5 % (+ noise allowance).
 Full-size properties: union of sample ranges, strip independence, energy / mean consistency.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -288,7 +289,10 @@ def test_tier_p_image_vs_live_checker(worlds, name):
 def test_tier_b_statistical_rmse(worlds, name):
     """RMSE protocol on linear pre-bloom radiance against an INDEPENDENT CPU estimator (mt19937_64)."""
     info, rt, ow = worlds(name, seed=3)
-    W, H, spp = 96, 54, 256
+    # the headline scene at the protocol's size (480x270 at 1024 spp; two checker renders of about 21 s on 16 threads);
+    # the other three at a size that keeps the suite short -- their protocol-size figures are on record in
+    # profiles/r03_rmse.json (tests/rmse_record.py)
+    W, H, spp = (480, 270, 1024) if name == "Cornell Smoke" else (96, 54, 256)
     img, _ = gpu_render(rt, W, H, spp)
     cpu_a, _ = ow.render(W, H, spp, seed=100, threads=16, rng_mode=1)
     cpu_b, _ = ow.render(W, H, spp, seed=200, threads=16, rng_mode=1)
@@ -297,6 +301,10 @@ def test_tier_b_statistical_rmse(worlds, name):
     disp = lambda x: np.clip(np.sqrt(np.maximum(x, 0)), 0, 1)
     r_cc, r_gc = rmse(disp(a), disp(b)), 0.5 * (rmse(disp(g), disp(a)) + rmse(disp(g), disp(b)))
     assert r_gc <= 1.15 * r_cc, (r_gc, r_cc)
+    if name == "Cornell Smoke":   # radiance is bounded by the emitter here (no fireflies): the linear values too
+        lin_cc, lin_gc = rmse(a, b), 0.5 * (rmse(g, a) + rmse(g, b))
+        assert lin_gc <= 1.15 * lin_cc, (lin_gc, lin_cc)
+        print(f"Cornell smoke {W}x{H} @ {spp}: display R_cc {r_cc:.6f} R_gc {r_gc:.6f}, linear R_cc {lin_cc:.6f} R_gc {lin_gc:.6f}")
     mg, mc = disp(g).mean(axis=(0, 1)), 0.5 * (disp(a).mean(axis=(0, 1)) + disp(b).mean(axis=(0, 1)))
     noise = np.abs(disp(a).mean(axis=(0, 1)) - disp(b).mean(axis=(0, 1)))
     assert (np.abs(mg - mc) <= 0.005 * mc + 2.0 * noise + 1e-4).all(), (mg, mc, noise)
@@ -473,6 +481,31 @@ def test_multi_handle_sum_through_rccl_world_of_one(monkeypatch):
     rts[0].trace_part_multi(rts[1:], img2.split(1)[0], 3, first_sample=0)
     ref2, _ = gpu_render(rts[0], 50, 30, 3, first=0)
     np.testing.assert_allclose(img2.buffer, ref2, rtol=1e-5, atol=1e-6)
+
+
+def test_multi_handle_join_failure_modes(monkeypatch):
+    """The two ways out of the device-side join. RCCL not there (nothing touched yet): the host sums the strips and
+    the image is right. A failure after the collectives were enqueued: the images may be partly reduced, so the call
+    is an error -- a host sum on top would count samples twice."""
+    from ray_tracing_amd import _ffi as F
+    info = scenarios.cornell_smoke()
+    rts = [RayTracer(info, device=0, seed=8) for _ in range(2)]
+    W, H, spp = 64, 40, 4
+    ref, _ = gpu_render(rts[0], W, H, spp, first=1)
+    monkeypatch.setenv("MRT_MULTI_FORCE_RCCL", "1")
+    monkeypatch.setenv("MRT_MULTI_INJECT_FAILURE", "load")
+    img = ParallelImage.new_black(W, H)
+    st = rts[0].trace_part_multi(rts[1:], img.split(1)[0], spp, first_sample=1)
+    assert st.paths == W * H * spp
+    np.testing.assert_allclose(img.buffer, ref, rtol=1e-5, atol=1e-6)
+    monkeypatch.setenv("MRT_MULTI_INJECT_FAILURE", "collective")
+    lib = F.load()
+    buf = np.zeros((H, W, 3), dtype=np.float32)
+    handles = (C.c_void_p * 2)(rts[0].world.handle, rts[1].world.handle)
+    rc = lib.mrt_render_accumulate_multi(handles, 2, buf.ctypes.data, W, H, 0, W, spp, 8, 1, None)
+    assert rc == F.MRT_ERR_DEVICE and b"ncclAllReduce" in lib.mrt_last_error()
+    monkeypatch.delenv("MRT_MULTI_INJECT_FAILURE")
+    monkeypatch.delenv("MRT_MULTI_FORCE_RCCL")
 
 
 def test_render_sharded_over_nccl_world_of_one(worlds):

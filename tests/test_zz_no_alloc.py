@@ -63,3 +63,33 @@ def test_noalloc_single_bounce_shader_and_argument_checks():
     host = np.zeros((45, 80, 3), dtype=np.float32)   # host memory is not a device accumulation buffer
     assert fn(h, host.ctypes.data, 80, 45, 0, 80, 1, 0, 0, None, None) == F.MRT_ERR_INVALID_ARGUMENT
     assert lib.mrt_render_accumulate_device(h, host.ctypes.data, 80, 45, 0, 80, 1, 0, 0, None, None) == F.MRT_ERR_INVALID_ARGUMENT
+
+
+def test_noalloc_leaves_the_free_device_memory_unchanged():
+    """On a scene that has never rendered (so the allocating entry point's pool does not exist yet) the call must not
+    change the device's free memory, on the first call or on a second, smaller one. A warm-up render of ANOTHER scene
+    handle comes first: the runtime itself reserves memory the first time a kernel with a private segment runs on a
+    queue, which is no allocation of this library's."""
+    import torch
+    lib = F.load()
+    fn = lib.mrt_render_accumulate_device_noalloc
+    info = scenarios.cornell_smoke()
+    warm = RayTracer(info, device=0, seed=1)
+    buf = torch.zeros((360, 640, 3), dtype=torch.float32, device="cuda:0")
+    small = torch.zeros((61, 97, 3), dtype=torch.float32, device="cuda:0")
+    st = F.Stats()
+    assert fn(warm.world.handle, buf.data_ptr(), 640, 360, 0, 640, 1, 1, 0, None, C.byref(st)) == F.MRT_OK
+    fresh = RayTracer(info, device=0, seed=5)      # created (scene data uploaded), never rendered
+    torch.cuda.synchronize()
+    for tensor, w, h, spp in ((buf, 640, 360, 3), (small, 97, 61, 2)):
+        free_before, _ = torch.cuda.mem_get_info(0)
+        assert fn(fresh.world.handle, tensor.data_ptr(), w, h, 0, w, spp, 5, 0, None, C.byref(st)) == F.MRT_OK, lib.mrt_last_error()
+        torch.cuda.synchronize()
+        free_after, _ = torch.cuda.mem_get_info(0)
+        assert free_after == free_before, (free_before, free_after)
+        assert st.paths == w * h * spp
+    # the allocating entry point, by contrast, makes the scene's pool on its first call
+    free_before, _ = torch.cuda.mem_get_info(0)
+    assert lib.mrt_render_accumulate_device(fresh.world.handle, buf.data_ptr(), 640, 360, 0, 640, 1, 5, 0, None, C.byref(st)) == F.MRT_OK
+    free_after, _ = torch.cuda.mem_get_info(0)
+    assert free_after < free_before
