@@ -54,7 +54,9 @@ def parse_args(argv=None):
     ap.add_argument("--pool-slots", type=int, default=0)
     ap.add_argument("--segments-per-launch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=64)
+    ap.add_argument("--cpu-spp", type=int, default=64, help="samples per pixel of the CPU baseline's sample of the workload")
+    ap.add_argument("--cpu-ref8-spp", type=int, default=0,
+                    help="samples per pixel of the eight-thread (reference layout) CPU leg; default cpu-spp / 8")
     ap.add_argument("--post", action="store_true", help="also time bloom + to_image on the device-resident image")
     return ap.parse_args(argv)
 
@@ -116,15 +118,26 @@ def launch_ranks(args) -> int:
 
 
 def cpu_baseline(info, width, height, spp, threads, label):
-    """Times the CPU checker (a C++ port of the reference's CPU path) on a bounded sample."""
+    """Times the CPU checker (a C++ port of the reference's CPU path) on a bounded sample, in sample-range
+    chunks with a progress line on stderr (a slow scene would otherwise look hung)."""
+    import numpy as np
     from tests.oracle_ffi import OracleWorld
 
     ow = OracleWorld(info)
+    accum = np.zeros((height, width, 3), dtype=np.float32)
+    paths = rays = 0
     t0 = time.perf_counter()
-    _, st = ow.render(width, height, spp, seed=0, threads=threads)
+    done = 0
+    chunk = max(1, spp // 8)
+    while done < spp:
+        n = min(chunk, spp - done)
+        _, st = ow.render(width, height, n, seed=0, first_sample=done, threads=threads, accum=accum)
+        paths, rays, done = paths + st.paths, rays + st.rays, done + n
+        print(f"[cpu baseline] {label}: {done}/{spp} spp on {threads} threads, {time.perf_counter() - t0:.1f} s",
+              file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
-    return {"value": st.paths / dt / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
-            "mrays_per_s": st.rays / dt / 1e6, "seconds": dt,
+    return {"value": paths / dt / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
+            "mrays_per_s": rays / dt / 1e6, "seconds": dt,
             "sample": f"{label} {width}x{height} @ {spp} spp, {threads} threads over vertical strips "
                       f"(threaded_render layout)"}
 
@@ -162,19 +175,28 @@ def native_checker_build():
 
 
 def host_description():
-    model = "unknown"
+    """The host CPU as /proc/cpuinfo names it. A virtualised host may show only the family name under
+    "model name", so the numeric family / model / stepping, which identify the part, are kept too."""
+    fields = {}
     try:
         for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
+            if ":" not in line:
+                if fields:
+                    break          # end of the first processor's block
+                continue
+            k, v = (x.strip() for x in line.split(":", 1))
+            if k in ("model name", "vendor_id", "cpu family", "model", "stepping", "cache size", "cpu MHz"):
+                fields.setdefault(k, v)
     except OSError:
         pass
     try:
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
-    return {"cpu_model": model, "nproc": os.cpu_count() or 1, "usable_cores": usable}
+    model = fields.get("model name", "unknown")
+    ident = " ".join(f"{k} {fields[k]}" for k in ("vendor_id", "cpu family", "model", "stepping") if k in fields)
+    return {"cpu_model": f"{model} ({ident}; cache {fields.get('cache size', '?')}; {fields.get('cpu MHz', '?')} MHz)",
+            "nproc": os.cpu_count() or 1, "usable_cores": usable}
 
 
 def committed_profile(workload_key):
@@ -454,8 +476,8 @@ def main():
                 build = native_checker_build()
                 cb = cpu_baseline(info, W, H, args.cpu_spp, threads, label)
                 # the reference's own layout: eight worker threads over eight vertical strips (ray_tracer.rs:496-497)
-                ref8 = cpu_baseline(info, W, H, max(1, args.cpu_spp // 8), 8, label)
-                cb["reference_layout_8_threads"] = {k: ref8[k] for k in ("value", "unit", "cores", "seconds", "sample")}
+                ref8 = cpu_baseline(info, W, H, args.cpu_ref8_spp or max(1, args.cpu_spp // 8), 8, label)
+                cb["reference_layout_8_threads"] = {k: ref8[k] for k in ("value", "unit", "cores", "seconds", "sample", "mrays_per_s")}
                 cb["host"] = host
                 cb["build"] = build
                 out["cpu_baseline"] = cb
