@@ -629,11 +629,18 @@ __device__ __forceinline__ uint32_t* dynamic_lds() {
     return mrt_dynamic_lds;
 }
 struct OctCursor {
-    uint32_t* anc;      // this lane's column of a [OCT_ANC_LEVELS][threads per workgroup] array
+    uint2* anc;         // this lane's column of a [OCT_ANC_LEVELS][threads per workgroup] array: (child link, child kinds) of a parent
     uint32_t stride;    // threads per workgroup
     int32_t x, y, z;    // cell of the previous lookup
     uint32_t leaf_exp;  // size exponent of the node it returned
-    bool valid;
+    bool valid;         // the remembered path is in use (oct_cursor_start)
+};
+// What a lookup returns: the leaf or empty node that contains the cell -- its kind (MRT_OCT_EMPTY, MRT_OCT_LEAF, or
+// OCT_LEAF_VOLUME for a leaf whose voxel is a volume), its size exponent and its index in the node array. The
+// voxel record index of a leaf is that node's link, read only by the caller that needs it (the end of a walk).
+constexpr uint32_t OCT_LEAF_VOLUME = 3;
+struct OctCell {
+    uint32_t kind, size, node;
 };
 // One node, by a load that names the global address space (a node array whose address went through a register
 // pin has lost that knowledge, and a generic-space load counts against both memory counters).
@@ -641,33 +648,59 @@ __device__ __forceinline__ DOctNode oct_node_at(const DOctNode* nodes, uint32_t 
     const uint64_t raw = ((const __attribute__((address_space(1))) uint64_t*)nodes)[i];
     return DOctNode{(uint32_t)raw, (int32_t)(raw >> 32)};
 }
-__device__ __forceinline__ DOctNode oct_chunk_near(const DOctNode* nodes, uint32_t root, uint32_t world_log2, OctCursor& c,
-                                                   int32_t x, int32_t y, int32_t z) {
-    DOctNode n;
-    bool from_root = true;
-    if (c.valid) {
-        const uint32_t diff = (uint32_t)((x ^ c.x) | (y ^ c.y) | (z ^ c.z));
-        const uint32_t h = 32u - (uint32_t)__clz((int)diff);  // cells agree above bit h - 1 (__clz(0) = 32)
-        const uint32_t s = h > c.leaf_exp + 1 ? h : c.leaf_exp + 1;  // smallest remembered parent that holds both
-        if (s <= world_log2) {
-            const uint32_t cs = s - 1;
-            const uint32_t ci = ((((uint32_t)x >> cs) & 1u) << 2) | ((((uint32_t)y >> cs) & 1u) << 1) | (((uint32_t)z >> cs) & 1u);
-            n = oct_node_at(nodes, c.anc[s * c.stride] + ci);
-            from_root = false;
-        }
+// A parent's record carries the kinds of its eight children (two bits each, DOctNode::kind_size bits 16..31), so
+// the descent reads a node only to enter a child that is itself a parent: a step to a sibling leaf or empty cell
+// -- half of all steps -- is answered from the remembered parent alone, with no access to memory, and the chain
+// of dependent loads per step, which bounds the walk, is shorter by one everywhere else.
+// The walk's lookup: the cursor always holds a remembered path (oct_cursor_start put the root there), so the
+// descent starts at the smallest remembered parent that contains both the previous cell and the new one.
+__device__ __forceinline__ OctCell oct_chunk_near(const DOctNode* nodes, OctCursor& c, int32_t x, int32_t y, int32_t z) {
+    const uint32_t diff = (uint32_t)((x ^ c.x) | (y ^ c.y) | (z ^ c.z));
+    const uint32_t h = 32u - (uint32_t)__clz((int)diff);   // cells agree above bit h - 1 (__clz(0) = 32)
+    uint32_t s = h > c.leaf_exp + 1 ? h : c.leaf_exp + 1;  // smallest remembered parent that holds both
+    const uint2 e = c.anc[s * c.stride];
+    uint32_t link = e.x, kinds = e.y, ci, k;
+    for (;;) {
+        s -= 1;
+        ci = ((((uint32_t)x >> s) & 1u) << 2) | ((((uint32_t)y >> s) & 1u) << 1) | (((uint32_t)z >> s) & 1u);
+        k = (kinds >> (2u * ci)) & 3u;
+        if (k != MRT_OCT_PARENT) break;
+        const DOctNode n = oct_node_at(nodes, link + ci);
+        link = (uint32_t)n.link, kinds = n.kind_size >> 16;
+        c.anc[s * c.stride] = uint2{link, kinds};
     }
-    if (from_root) n = oct_node_at(nodes, root);
-    while ((n.kind_size & 0xFF) == MRT_OCT_PARENT) {
-        const uint32_t s = n.kind_size >> 8;
-        c.anc[s * c.stride] = (uint32_t)n.link;
-        const uint32_t cs = s - 1;
-        const uint32_t ci = ((((uint32_t)x >> cs) & 1u) << 2) | ((((uint32_t)y >> cs) & 1u) << 1) | (((uint32_t)z >> cs) & 1u);
-        n = oct_node_at(nodes, (uint32_t)n.link + ci);
+    c.x = x, c.y = y, c.z = z, c.leaf_exp = s;
+    return OctCell{k, s, link + ci};
+}
+// The same lookup from the root, without a remembered path: trees whose root is not a parent (one node) and
+// worlds of 2^OCT_ANC_LEVELS cells or more along an edge, which the cursor's array does not hold.
+__device__ OctCell oct_chunk_from_root(const DOctNode* nodes, uint32_t root, uint32_t world_log2, int32_t x, int32_t y, int32_t z) {
+    DOctNode n = oct_node_at(nodes, root);
+    if ((n.kind_size & 0xFF) != MRT_OCT_PARENT) return OctCell{(n.kind_size >> 16) & 3u, world_log2, root};
+    uint32_t s = world_log2;
+    for (;;) {
+        s -= 1;
+        const uint32_t ci = ((((uint32_t)x >> s) & 1u) << 2) | ((((uint32_t)y >> s) & 1u) << 1) | (((uint32_t)z >> s) & 1u);
+        const uint32_t k = ((n.kind_size >> 16) >> (2u * ci)) & 3u;
+        const uint32_t at = (uint32_t)n.link + ci;
+        if (k != MRT_OCT_PARENT) return OctCell{k, s, at};
+        n = oct_node_at(nodes, at);
     }
-    c.x = x, c.y = y, c.z = z;
-    c.leaf_exp = n.kind_size >> 8;
-    c.valid = world_log2 < (uint32_t)OCT_ANC_LEVELS;
-    return n;
+}
+// Puts the root on the cursor's remembered path, so that the first lookup of a walk descends from it like any other
+// from its smallest common parent. `cached` (the same for every lane that walks this tree): the tree has a parent
+// root and fits the cursor's array.
+__device__ __forceinline__ bool oct_cursor_start(const DOctNode* nodes, const DOctree& oc, OctCursor& c) {
+    const DOctNode n = oct_node_at(nodes, oc.root);
+    const bool cached = (n.kind_size & 0xFF) == MRT_OCT_PARENT && oc.world_log2 < (uint32_t)OCT_ANC_LEVELS;
+    if (cached) c.anc[oc.world_log2 * c.stride] = uint2{(uint32_t)n.link, n.kind_size >> 16};
+    c.x = 0, c.y = 0, c.z = 0, c.leaf_exp = oc.world_log2 - 1, c.valid = cached;
+    return cached;
+}
+template <bool CACHED>
+__device__ __forceinline__ OctCell oct_lookup(const DOctNode* nodes, const DOctree& oc, OctCursor& c, int32_t x, int32_t y, int32_t z) {
+    if constexpr (CACHED) return oct_chunk_near(nodes, c, x, y, z);
+    else return oct_chunk_from_root(nodes, oc.root, oc.world_log2, x, y, z);
 }
 // Rust `as i32`: toward zero, saturating, NaN -> 0 -- which is what v_cvt_i32_f64 does by itself
 // (a C++ cast leaves the out-of-range cases undefined, hence the instruction by name).
@@ -750,7 +783,7 @@ __device__ __forceinline__ int oct_handle_empty(OctVolume& vs, D3 cur, D3 d, D3&
 // ray_iteration (ray_trace.rs:86-560): walk leaf to leaf until a solid leaf is entered, or (VOL) a
 // volume's edge effect or free path stops the ray. `cur` starts at the ray origin. Returns false
 // for None. `code`: see OCT_SUB.
-template <bool VOL>
+template <bool VOL, bool CACHED>
 __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels, const DOctree& oc, int32_t bx, int32_t by,
                                   int32_t bz, D3 origin, D3 d, int initial_normal, const Rng& g, uint32_t& entry, D3& hit_pos,
                                   int& code, int& voxel, OctCursor& cursor) {
@@ -763,15 +796,15 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
         return (uint32_t)x < ws && (uint32_t)y < ws && (uint32_t)z < ws;
     };
     if (!in_range(bx, by, bz)) return false;  // get_chunk(..).expect("out of range")
-    DOctNode chunk = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, bx, by, bz);
-    uint32_t csz = chunk.kind_size >> 8;
+    const OctCell chunk = oct_lookup<CACHED>(nodes, oc, cursor, bx, by, bz);
+    uint32_t csz = chunk.size;
     bx = floor_size(bx, csz), by = floor_size(by, csz), bz = floor_size(bz, csz);
     D3 cur = origin;
     OctVolume vs{false, 0.0, 0.0, {0.0, 0.0, 0.0}, -1};
     // the starting cell: a volume starts the free-path walk, a solid is ignored (ray_trace.rs:476-510)
     if constexpr (VOL) {
-        if ((chunk.kind_size & 0xFF) == MRT_OCT_LEAF && voxels[chunk.link].kind == MRT_VOX_VOLUME) {
-            if (oct_handle_volume(voxels, chunk.link, vs, cur, d, initial_normal, g, entry, hit_pos, code, voxel) == OCT_STOP)
+        if (chunk.kind == OCT_LEAF_VOLUME) {
+            if (oct_handle_volume(voxels, oct_node_at(nodes, chunk.node).link, vs, cur, d, initial_normal, g, entry, hit_pos, code, voxel) == OCT_STOP)
                 return true;
         }
     }
@@ -813,84 +846,83 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
         // get_chunk_size panics out of range; this also covers the reference's earlier check of the
         // cell below the old block on the way back (the other two coordinates are the block's own)
         if (!in_range(lx, ly, lz)) return false;
-        const DOctNode node = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, lx, ly, lz);
-        const uint32_t ncs = node.kind_size >> 8;
+        const OctCell node = oct_lookup<CACHED>(nodes, oc, cursor, lx, ly, lz);
+        const uint32_t ncs = node.size;
         const int32_t na = forward ? la : ba - (1 << ncs);
         bx = ax0 ? na : floor_size(cx, ncs);
         by = ax1 ? na : floor_size(cy, ncs);
         bz = ax2 ? na : floor_size(cz, ncs);
         const int normal_code = (ax0 ? 0 : (ax1 ? 2 : 4)) + (forward ? 0 : 1);
         // handle_hit, ray_trace.rs:202-221
-        if ((node.kind_size & 0xFF) == MRT_OCT_LEAF) {
-            bool is_volume = false;
-            if constexpr (VOL) is_volume = voxels[node.link].kind == MRT_VOX_VOLUME;
+        if (node.kind != MRT_OCT_EMPTY) {
+            const bool is_volume = VOL && node.kind == OCT_LEAF_VOLUME;
             if (!is_volume) {  // StopIterationSolid with the voxel's own material
                 hit_pos = cur;
-                code = normal_code, voxel = node.link;
+                code = normal_code, voxel = oct_node_at(nodes, node.node).link;
                 return true;
             }
             if constexpr (VOL) {
-                if (oct_handle_volume(voxels, node.link, vs, cur, d, normal_code, g, entry, hit_pos, code, voxel) == OCT_STOP)
+                if (oct_handle_volume(voxels, oct_node_at(nodes, node.node).link, vs, cur, d, normal_code, g, entry, hit_pos, code, voxel) == OCT_STOP)
                     return true;
             }
         } else if constexpr (VOL) {
             if (oct_handle_empty(vs, cur, d, hit_pos, code, voxel) == OCT_STOP) return true;
         }
-        step = 1 << (node.kind_size >> 8);
+        step = 1 << ncs;
     }
     return false;  // "Max number of iterations reached"
 }
 
 // FastOctTree::trace_ray (ray_trace.rs:561-683); `d` is the normalised direction.
-template <bool VOL>
+template <bool VOL, bool CACHED>
 __device__ bool oct_trace_ray(const DOctNode* nodes, const mrt_voxel* voxels, const DOctree& oc, D3 o, D3 d, const Rng& g,
                               uint32_t& entry, D3& hit_pos, int& code, int& voxel) {
     const double ws = (double)(1u << oc.world_log2);
     // (the workgroup's dynamic LDS: kernels with octree code are launched with lds_bytes() of it)
-    OctCursor cursor{dynamic_lds() + threadIdx.x, blockDim.x, 0, 0, 0, 0, false};
-    if (o.x >= 0.0 && o.x <= ws && o.y >= 0.0 && o.y <= ws && o.z >= 0.0 && o.z <= ws) {
-        return oct_ray_iteration<VOL>(nodes, voxels, oc, f64_as_i32(o.x), f64_as_i32(o.y), f64_as_i32(o.z), o, d, 1 /* unit_x */,
-                                      g, entry, hit_pos, code, voxel, cursor);
-    }
-    double v0 = (0.0 - o.x) / d.x, v1 = (ws - o.x) / d.x;
-    double v2 = (0.0 - o.y) / d.y, v3 = (ws - o.y) / d.y;
-    double v4 = (0.0 - o.z) / d.z, v5 = (ws - o.z) / d.z;
-    // entry = the largest of the per-axis near planes, exit = the smallest of the far planes
-    int min_x = v0 < v1 ? 0 : 1, min_y = v2 < v3 ? 2 : 3, min_z = v4 < v5 ? 4 : 5;
-    double nx = v0 < v1 ? v0 : v1, fx = v0 < v1 ? v1 : v0;
-    double ny = v2 < v3 ? v2 : v3, fy = v2 < v3 ? v3 : v2;
-    double nz = v4 < v5 ? v4 : v5, fz = v4 < v5 ? v5 : v4;
-    int min_index;
-    double vmin;
-    if (nx > ny && nx > nz) min_index = min_x, vmin = nx;
-    else if (ny > nx && ny > nz) min_index = min_y, vmin = ny;
-    else min_index = min_z, vmin = nz;
-    double vmax;
-    if (fx < fy && fx < fz) vmax = fx;
-    else if (fy < fx && fy < fz) vmax = fy;
-    else vmax = fz;
-    if (!(vmax >= vmin && vmin >= 0.0)) return false;
-    D3 position = o + vmin * d;
-    // BLOCK_OFFSETS: -1 on the axis of a "far side" entry plane (indices 1, 3, 5)
-    int32_t bx = f64_as_i32(position.x) + (min_index == 1 ? -1 : 0);
-    int32_t by = f64_as_i32(position.y) + (min_index == 3 ? -1 : 0);
-    int32_t bz = f64_as_i32(position.z) + (min_index == 5 ? -1 : 0);
-    const int32_t wsi = (int32_t)(1u << oc.world_log2);
-    // self.get(block as u32): a negative coordinate wraps and is out of range -> None
-    if (bx >= 0 && bx < wsi && by >= 0 && by < wsi && bz >= 0 && bz < wsi) {
-        DOctNode n = oct_chunk_near(nodes, oc.root, oc.world_log2, cursor, bx, by, bz);
-        if ((n.kind_size & 0xFF) == MRT_OCT_LEAF) {
-            bool is_volume = false;
-            if constexpr (VOL) is_volume = voxels[n.link].kind == MRT_VOX_VOLUME;
-            if (!is_volume) {  // a solid entry voxel is the hit (ray_trace.rs:653-657)
+    OctCursor cursor{reinterpret_cast<uint2*>(dynamic_lds()) + threadIdx.x, blockDim.x, 0, 0, 0, 0, false};
+    if constexpr (CACHED) oct_cursor_start(nodes, oc, cursor);
+    // where the walk starts: at the origin when it lies in the world's cube, else where the ray enters the cube
+    D3 position = o;
+    int32_t bx = f64_as_i32(o.x), by = f64_as_i32(o.y), bz = f64_as_i32(o.z);
+    int initial_normal = 1;  // unit_x
+    if (!(o.x >= 0.0 && o.x <= ws && o.y >= 0.0 && o.y <= ws && o.z >= 0.0 && o.z <= ws)) {
+        double v0 = (0.0 - o.x) / d.x, v1 = (ws - o.x) / d.x;
+        double v2 = (0.0 - o.y) / d.y, v3 = (ws - o.y) / d.y;
+        double v4 = (0.0 - o.z) / d.z, v5 = (ws - o.z) / d.z;
+        // entry = the largest of the per-axis near planes, exit = the smallest of the far planes
+        int min_x = v0 < v1 ? 0 : 1, min_y = v2 < v3 ? 2 : 3, min_z = v4 < v5 ? 4 : 5;
+        double nx = v0 < v1 ? v0 : v1, fx = v0 < v1 ? v1 : v0;
+        double ny = v2 < v3 ? v2 : v3, fy = v2 < v3 ? v3 : v2;
+        double nz = v4 < v5 ? v4 : v5, fz = v4 < v5 ? v5 : v4;
+        int min_index;
+        double vmin;
+        if (nx > ny && nx > nz) min_index = min_x, vmin = nx;
+        else if (ny > nx && ny > nz) min_index = min_y, vmin = ny;
+        else min_index = min_z, vmin = nz;
+        double vmax;
+        if (fx < fy && fx < fz) vmax = fx;
+        else if (fy < fx && fy < fz) vmax = fy;
+        else vmax = fz;
+        if (!(vmax >= vmin && vmin >= 0.0)) return false;
+        position = o + vmin * d;
+        // BLOCK_OFFSETS: -1 on the axis of a "far side" entry plane (indices 1, 3, 5)
+        bx = f64_as_i32(position.x) + (min_index == 1 ? -1 : 0);
+        by = f64_as_i32(position.y) + (min_index == 3 ? -1 : 0);
+        bz = f64_as_i32(position.z) + (min_index == 5 ? -1 : 0);
+        initial_normal = min_index;
+        const int32_t wsi = (int32_t)(1u << oc.world_log2);
+        // self.get(block as u32): a negative coordinate wraps and is out of range -> None
+        if (bx >= 0 && bx < wsi && by >= 0 && by < wsi && bz >= 0 && bz < wsi) {
+            const OctCell n = oct_lookup<CACHED>(nodes, oc, cursor, bx, by, bz);
+            if (n.kind != MRT_OCT_EMPTY && !(VOL && n.kind == OCT_LEAF_VOLUME)) {  // a solid entry voxel is the hit (ray_trace.rs:653-657)
                 hit_pos = position;
                 code = min_index;  // NORMALS[min_index]: 0 -x, 1 +x, 2 -y, 3 +y, 4 -z, 5 +z
-                voxel = n.link;
+                voxel = oct_node_at(nodes, n.node).link;
                 return true;
             }
         }
     }
-    return oct_ray_iteration<VOL>(nodes, voxels, oc, bx, by, bz, position, d, min_index, g, entry, hit_pos, code, voxel, cursor);
+    return oct_ray_iteration<VOL, CACHED>(nodes, voxels, oc, bx, by, bz, position, d, initial_normal, g, entry, hit_pos, code, voxel, cursor);
 }
 
 // Hittable for FastOctTree<Voxel> (fast_oct_tree/hittable.rs:10-68); `sr` is the object-space ray.
@@ -903,7 +935,10 @@ __device__ bool octree_hit(const DOctNode* nodes, const mrt_voxel* voxels, const
     D3 nd = normalize(sr.d);
     D3 hp;
     int code, voxel;
-    if (!oct_trace_ray<VOL>(nodes, voxels, oc, sr.o, nd, g, entry, hp, code, voxel)) return false;
+    // (`cached`, worked out by the host: the tree has a parent root and fits the walk's remembered path)
+    if (oc.cached ? !oct_trace_ray<VOL, true>(nodes, voxels, oc, sr.o, nd, g, entry, hp, code, voxel)
+                  : !oct_trace_ray<VOL, false>(nodes, voxels, oc, sr.o, nd, g, entry, hp, code, voxel))
+        return false;
     D3 dp = hp - sr.o;
     double t = sqrt(dot(dp, dp) / dot(sr.d, sr.d));
     if (!(t > t_min && t < t_max)) return false;  // strict, unlike the other shapes
@@ -2341,7 +2376,7 @@ constexpr int seg_block(bool wave) { return wave ? 64 : 256; }
 // exists, else the candidate-search arrays in the per-lane kernels (trees with octrees do not use
 // the candidate search).
 constexpr size_t lds_bytes(bool wave, int feat, int threads) {
-    if (feat & FEAT_OCTREE) return sizeof(uint32_t) * OCT_ANC_LEVELS * (size_t)threads;
+    if (feat & FEAT_OCTREE) return sizeof(uint2) * OCT_ANC_LEVELS * (size_t)threads;
     if (!wave) return sizeof(uint32_t) * (CAND_WORDS + 1) * (size_t)threads + sizeof(uint16_t) * CAND_QUEUE * (size_t)(threads / 64);
     return 0;
 }

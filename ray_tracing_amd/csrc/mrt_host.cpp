@@ -598,6 +598,23 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
                 }
                 s.oct_nodes.push_back(dn);
             }
+            // the kinds of a parent's children ride in the parent's record, a leaf's own code in its own
+            auto code_of = [&](const DOctNode& c) -> uint32_t {
+                const uint32_t k = c.kind_size & 0xFFu;
+                if (k != MRT_OCT_LEAF) return k;
+                return o.voxels[(uint32_t)c.link - voxel_base].kind == MRT_VOX_VOLUME ? 3u : (uint32_t)MRT_OCT_LEAF;
+            };
+            for (size_t k = base; k < s.oct_nodes.size(); ++k) {
+                DOctNode& dn = s.oct_nodes[k];
+                uint32_t kinds = 0;
+                if ((dn.kind_size & 0xFFu) == MRT_OCT_PARENT) {
+                    for (uint32_t c = 0; c < 8; ++c) kinds |= code_of(s.oct_nodes[(size_t)dn.link + c]) << (2u * c);
+                } else {
+                    kinds = code_of(dn);
+                }
+                dn.kind_size = (dn.kind_size & 0xFFFFu) | (kinds << 16);
+            }
+            dt.cached = (s.oct_nodes[base].kind_size & 0xFFu) == MRT_OCT_PARENT && dt.world_log2 < 16 ? 1u : 0u;
         }
         s.octree_has_volume.push_back(0);
         for (uint32_t v = 0; v < o.n_voxels; ++v) {

@@ -57,15 +57,19 @@ struct DImage {
 // Device octree node (8 bytes): nodes of one tree are stored breadth-first so that the eight
 // children of a parent are consecutive; `link` is the index of the first child (PARENT) or of the
 // voxel record (LEAF), both absolute indices into the shared pools.
+// In bits 16..31 of `kind_size` a parent carries the kinds of its eight children, two bits each (child c in bits
+// 16 + 2c: MRT_OCT_EMPTY, MRT_OCT_LEAF, MRT_OCT_PARENT, or 3 for a leaf whose voxel is a volume), so that a
+// descent reads a child only when it is itself a parent; a leaf carries its own code (1, or 3 for a volume voxel)
+// in bits 16..17.
 struct DOctNode {
-    uint32_t kind_size;  // kind | size << 8
+    uint32_t kind_size;  // kind | size << 8 | child kinds << 16
     int32_t link;
 };
 struct DOctree {
     uint32_t root;         // absolute index of the root node
     uint32_t world_log2;   // root size (log2 of the world edge)
     uint32_t n_nodes;      // 0: empty tree (no bounding box)
-    uint32_t pad;
+    uint32_t cached;       // 1: the root is a parent and world_log2 < 16, so a walk can keep its path of parents (16 levels) per lane
 };
 
 // Camera::new output (camera.rs:44-76)
