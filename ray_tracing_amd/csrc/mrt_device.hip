@@ -814,6 +814,10 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
     const bool fx = d.x >= 0.0, fy = d.y >= 0.0, fz = d.z >= 0.0;
     const D3 inv{rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z)};
     int32_t step = 1 << csz;  // get_step_size of the current block
+    // A solid hit leaves the loop and is written out after it: assigned inside, `hit_pos` would be a value carried
+    // around the loop, three 64-bit copies per step.
+    uint32_t solid_node = ~0u;
+    int solid_code = 0;
     for (int it = 0; it < 3000; ++it) {
 #ifdef MRT_STAMPS
         {
@@ -826,7 +830,7 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
         double tx = ((double)(bx + (px ? step : 0)) - cur.x) * inv.x;
         double ty = ((double)(by + (py ? step : 0)) - cur.y) * inv.y;
         double tz = ((double)(bz + (pz ? step : 0)) - cur.z) * inv.z;
-        if (tx < 0.0 || ty < 0.0 || tz < 0.0) return false;
+        if (tx < 0.0 || ty < 0.0 || tz < 0.0) break;
         // The reference has six copies of this step (axis x sign, ray_trace.rs:222-470); here the axis
         // is a value, so the lanes of a wave take one path and issue one lookup together. The
         // smallest t picks the axis, ties fall to z (ray_trace.rs:398).
@@ -845,7 +849,7 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
         const int32_t lx = ax0 ? la : cx, ly = ax1 ? la : cy, lz = ax2 ? la : cz;
         // get_chunk_size panics out of range; this also covers the reference's earlier check of the
         // cell below the old block on the way back (the other two coordinates are the block's own)
-        if (!in_range(lx, ly, lz)) return false;
+        if (!in_range(lx, ly, lz)) break;
         const OctCell node = oct_lookup<CACHED>(nodes, oc, cursor, lx, ly, lz);
         const uint32_t ncs = node.size;
         const int32_t na = forward ? la : ba - (1 << ncs);
@@ -857,9 +861,8 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
         if (node.kind != MRT_OCT_EMPTY) {
             const bool is_volume = VOL && node.kind == OCT_LEAF_VOLUME;
             if (!is_volume) {  // StopIterationSolid with the voxel's own material
-                hit_pos = cur;
-                code = normal_code, voxel = oct_node_at(nodes, node.node).link;
-                return true;
+                solid_node = node.node, solid_code = normal_code;
+                break;
             }
             if constexpr (VOL) {
                 if (oct_handle_volume(voxels, oct_node_at(nodes, node.node).link, vs, cur, d, normal_code, g, entry, hit_pos, code, voxel) == OCT_STOP)
@@ -869,6 +872,11 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
             if (oct_handle_empty(vs, cur, d, hit_pos, code, voxel) == OCT_STOP) return true;
         }
         step = 1 << ncs;
+    }
+    if (solid_node != ~0u) {
+        hit_pos = cur;
+        code = solid_code, voxel = oct_node_at(nodes, solid_node).link;
+        return true;
     }
     return false;  // "Max number of iterations reached"
 }
@@ -1017,13 +1025,15 @@ __device__ __forceinline__ bool leaf_hit(SceneRef sv, int kind, int bkind, int o
     }
     return false;
 }
-// Leaf test from an object record.
+// Leaf test from an object record (the queries against the light list). A translated object takes the general
+// transform here -- not the walk's shortcut: with the shortcut's code in the light query the headline kernel
+// measured 2.4 % slower, and no shipped scene has a transformed light; surface_at is told (`shortcut` false).
 template <int FEAT, class OP>
 __device__ __forceinline__ bool object_hit(SceneRef sv, OP ob, const RayD& ray, D3 inv_world, double t_min,
                                            double t_max, const Rng& g, uint32_t medium_dim, uint32_t& oct_entry, double& t,
                                            int& sub, D3& pos) {
-    return leaf_hit<FEAT>(sv, ob->kind, ob->gkind, ob->octree, &ob->p[0], ob->p[9], ob->identity != 0, &ob->to_object, ray,
-                          inv_world, t_min, t_max, g, medium_dim, oct_entry, t, sub, pos, ob->translation != 0);
+    return leaf_hit<FEAT>(sv, ob->kind, ob->gkind, ob->octree, &ob->p[0], ob->p[9], ob->identity == 1, &ob->to_object, ray,
+                          inv_world, t_min, t_max, g, medium_dim, oct_entry, t, sub, pos);
 }
 // Leaf test of the wave-synchronous walk from a self-contained node record (scalar operands). `kind` and `flags`
 // are the record's, which the walk holds already.
@@ -1602,12 +1612,13 @@ __device__ void surface_uv(OP sh, const Surface& s, double& u, double& v) {
     }
 }
 template <int FEAT, class OP>
-__device__ void surface_at(OP ob, const RayD& ray, double t, int sub, D3 oct_pos, Surface& s) {
+__device__ void surface_at(OP ob, const RayD& ray, double t, int sub, D3 oct_pos, Surface& s, bool shortcut = true) {
     // (the object-space ray the leaf test used: an untransformed object sees the world ray, a translated one the
     // world direction from the moved origin, see leaf_hit -- t and the hit point then come from ONE direction)
     RayD sr = ray;
-    if (ob->translation) sr.o = {ray.o.x + ob->to_object.r[0][3], ray.o.y + ob->to_object.r[1][3], ray.o.z + ob->to_object.r[2][3]};
-    else if (!ob->identity) sr = xform_ray(&ob->to_object, false, ray);
+    const int xf = ob->identity;
+    if (xf == 2 && shortcut) sr.o = {ray.o.x + ob->to_object.r[0][3], ray.o.y + ob->to_object.r[1][3], ray.o.z + ob->to_object.r[2][3]};
+    else if (xf != 1) sr = xform_ray(&ob->to_object, false, ray);
     OP sh = ob;
     auto p = sh->p;
     s.pos_obj = ray_at(sr, t);
@@ -1651,7 +1662,7 @@ __device__ void surface_at(OP ob, const RayD& ray, double t, int sub, D3 oct_pos
 }
 template <class OP>
 __device__ __forceinline__ D3 normal_to_world(OP ob, D3 n) {  // hittable.rs:215-220
-    if (ob->identity) return n;
+    if (ob->identity) return n;  // (a pure translation too: its normal matrix is exactly the identity)
     // cgmath Matrix3 * Vector3 = col0*x + col1*y + col2*z; normal_m holds rows
     return {(ob->normal_m[0][0] * n.x + ob->normal_m[0][1] * n.y) + ob->normal_m[0][2] * n.z,
             (ob->normal_m[1][0] * n.x + ob->normal_m[1][1] * n.y) + ob->normal_m[1][2] * n.z,
@@ -1659,7 +1670,10 @@ __device__ __forceinline__ D3 normal_to_world(OP ob, D3 n) {  // hittable.rs:215
 }
 template <class OP>
 __device__ __forceinline__ D3 point_to_world(OP ob, D3 p) {
-    if (ob->identity) return p;
+    const int xf = ob->identity;
+    if (xf == 1) return p;
+    // (a pure translation: the products with the exact 0s and 1s of its linear part leave p + t, rounded once)
+    if (xf == 2) return {p.x + ob->to_world.r[0][3], p.y + ob->to_world.r[1][3], p.z + ob->to_world.r[2][3]};
     return apply(&ob->to_world, p);
 }
 
@@ -1875,7 +1889,7 @@ __device__ void shape_generate(OP sh, D3 origin, double time, const Rng& g, doub
 template <int FEAT, class OP>
 __device__ void object_generate(OP ob, D3 origin, double time, const Rng& g, double ua, double ub, AreaInfo& out,
                                 const D3* unit_vec = nullptr) {
-    if (ob->identity) {
+    if (ob->identity == 1) {
         shape_generate<FEAT>(ob, origin, time, g, ua, ub, out, unit_vec);
         // the reference still routes every vector through the (identity) inverse
         D3 o = out.to_area.o;
@@ -1926,7 +1940,7 @@ __device__ bool light_pdf_value(SceneRef sv, const RayD& ray, const Rng& g, uint
     // (a one-entry list: the light's record is the same for every lane and is read with scalar loads)
     auto value_at = [&](auto ob) {
         Surface s;
-        surface_at<LF>(ob, ray, best_t, best_sub, D3{0.0, 0.0, 0.0}, s);
+        surface_at<LF>(ob, ray, best_t, best_sub, D3{0.0, 0.0, 0.0}, s, false);
         D3 hit_pos = point_to_world(ob, s.pos_obj);
         D3 hit_n = normal_to_world(ob, s.n_obj);
         D3 to_light = hit_pos - ray.o;
@@ -1934,7 +1948,7 @@ __device__ bool light_pdf_value(SceneRef sv, const RayD& ray, const Rng& g, uint
         if (light_cos >= 0.000001) {
             // Object::prob applies the INVERSE transform to the ray (hittable.rs:284-287)
             RayD pr{ray.o, normalize(to_light), best_t};
-            RayD tr = xform_ray(&ob->to_world, ob->identity != 0, pr);
+            RayD tr = xform_ray(&ob->to_world, ob->identity == 1, pr);
             value = shape_prob<LF>(ob, tr);
         } else {
             value = 0.0;

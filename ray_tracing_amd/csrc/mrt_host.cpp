@@ -735,10 +735,12 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
         }
         r.to_object = ob.to_object, r.to_world = ob.to_world;
         std::memcpy(r.normal_m, ob.normal_m, sizeof(r.normal_m));
-        r.translation = ob.identity ? 0 : 1;
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b)
-                if (ob.to_object.r[a][b] != (a == b ? 1.0 : 0.0)) r.translation = 0;
+        if (!ob.identity) {
+            r.identity = 2;  // a pure translation, unless the linear part says otherwise
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b)
+                    if (ob.to_object.r[a][b] != (a == b ? 1.0 : 0.0)) r.identity = 0;
+        }
         return r;
     };
     for (const DObject& ob : s.objects) s.obj_recs.push_back(mk_rec(ob));
@@ -831,7 +833,7 @@ int flatten_scene(const mrt_scene_desc* d, FlatScene* out, std::string* err) {
             for (int a = 0; a < 3; ++a)
                 for (int b = 0; b < 3; ++b) translation = translation && r.to_object.r[a][b] == (a == b ? 1.0 : 0.0);
             l.kind = r.kind, l.gkind = r.gkind, l.octree = r.octree;
-            l.identity = r.identity ? 1 : (translation ? 2 : 0);
+            l.identity = r.identity == 1 ? 1 : (translation ? 2 : 0);
             std::memcpy(l.p, r.p, sizeof(l.p));
         }
         // self-contained node records for the wave-synchronous walk

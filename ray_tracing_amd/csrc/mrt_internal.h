@@ -166,12 +166,12 @@ static_assert(sizeof(DNodeRec) == 256, "DNodeRec must be 256 bytes");
 struct DObjRec {
     int32_t kind;       // shape kind of the object (CONSTANT_MEDIUM for media)
     int32_t gkind;      // kind of the geometry: the boundary's for media, else `kind`
-    int32_t identity;   // object transform is the identity
+    int32_t identity;   // object transform: 1 the identity, 2 a pure translation (linear part exactly the identity), 0 any other
     int32_t octree;     // octree index for OCTREE shapes
     int32_t mat_kind;   // material kind (phase function for media); unused for OCTREE
     int32_t texture;    // texture index of the material
     int32_t tex_solid;  // 1: the texture is a SolidColor and `color` holds its value
-    int32_t translation;  // the object transform is a pure translation (linear part exactly the identity), not the identity
+    int32_t pad;
     float color[3];     // SolidColor value, or the Dielectric colour
     int32_t pad2;
     double fuzz, index_refraction;
