@@ -1653,6 +1653,23 @@ int oracle_sample_radiance(void* scene, uint32_t width, uint32_t height, const i
     return MRT_OK;
 }
 
+// Steps of the octree walk (ray_iteration, fast_oct_tree/ray_trace.rs:200) that one nearest_hit of each ray takes: a
+// diagnostic for walk-length statistics, not a result of the reference.
+int oracle_octree_steps(void* scene, const double* rays, size_t n, uint64_t seed, uint32_t* steps_out) {
+    auto* s = static_cast<Scene*>(scene);
+    if (!s || !rays || !steps_out) return MRT_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < n; ++i) {
+        g_rng = RngCtx{};
+        g_rng.key = path_key(seed, i, 0);
+        const double* r = rays + 7 * i;
+        Ray ray{{r[0], r[1], r[2]}, {r[3], r[4], r[5]}, r[6]};
+        const unsigned long long before = octref::oct_step_counter();
+        (void)s->world.nearest_hit(ray, 0.001f, std::numeric_limits<float>::max());
+        steps_out[i] = (uint32_t)(octref::oct_step_counter() - before);
+    }
+    return MRT_OK;
+}
+
 // Probe of LambertianPDF::generate (pdf.rs:234-282) on n given surface points: point i has normal
 // normals[i], the incoming ray's time in_times[i], and draws from the stream of pixel index i, sample 0,
 // segment `seg`. Outputs: the sampled direction, the mixture "pdf" value, the branch drawn (0 cosine,

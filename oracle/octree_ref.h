@@ -147,6 +147,11 @@ struct HitInfo {
 };
 // Voxel table and random source for volume voxels. rand01(user, 2 * n + which): the uniform of the
 // n-th volume entry of this walk; which = 0 edge effect (ray_trace.rs:159), 1 free path (:168).
+// Steps of ray_iteration made by the calling thread (a diagnostic for walk-length statistics).
+inline unsigned long long& oct_step_counter() {
+    static thread_local unsigned long long n = 0;
+    return n;
+}
 struct VolumeCtx {
     const mrt_voxel* voxels = nullptr;
     double (*rand01)(void* user, uint32_t index) = nullptr;
@@ -383,6 +388,7 @@ struct Tree {
         }
         double sign_vec[3] = {std::signbit(d[0]) ? 0.0 : 1.0, std::signbit(d[1]) ? 0.0 : 1.0, std::signbit(d[2]) ? 0.0 : 1.0};
         for (int it = 0; it < 3000; ++it) {
+            ++oct_step_counter();
             int step_size = get_step_size(block);
             if (step_size < 0) return false;  // get_step_size would panic; in_range is checked right after
             if (!in_range(block)) return false;

@@ -631,9 +631,6 @@ __device__ __forceinline__ uint32_t* dynamic_lds() {
 struct OctCursor {
     uint2* anc;         // this lane's column of a [OCT_ANC_LEVELS][threads per workgroup] array: (child link, child kinds) of a parent
     uint32_t stride;    // threads per workgroup
-    int32_t x, y, z;    // cell of the previous lookup
-    uint32_t leaf_exp;  // size exponent of the node it returned
-    bool valid;         // the remembered path is in use (oct_cursor_start)
 };
 // What a lookup returns: the leaf or empty node that contains the cell -- its kind (MRT_OCT_EMPTY, MRT_OCT_LEAF, or
 // OCT_LEAF_VOLUME for a leaf whose voxel is a volume), its size exponent and its index in the node array. The
@@ -652,12 +649,15 @@ __device__ __forceinline__ DOctNode oct_node_at(const DOctNode* nodes, uint32_t 
 // the descent reads a node only to enter a child that is itself a parent: a step to a sibling leaf or empty cell
 // -- half of all steps -- is answered from the remembered parent alone, with no access to memory, and the chain
 // of dependent loads per step, which bounds the walk, is shorter by one everywhere else.
-// The walk's lookup: the cursor always holds a remembered path (oct_cursor_start put the root there), so the
-// descent starts at the smallest remembered parent that contains both the previous cell and the new one.
-__device__ __forceinline__ OctCell oct_chunk_near(const DOctNode* nodes, OctCursor& c, int32_t x, int32_t y, int32_t z) {
-    const uint32_t diff = (uint32_t)((x ^ c.x) | (y ^ c.y) | (z ^ c.z));
-    const uint32_t h = 32u - (uint32_t)__clz((int)diff);   // cells agree above bit h - 1 (__clz(0) = 32)
-    uint32_t s = h > c.leaf_exp + 1 ? h : c.leaf_exp + 1;  // smallest remembered parent that holds both
+// The walk's lookup: the lane's remembered path holds the parents of the node that the previous lookup returned
+// (oct_cursor_start put the root there), which the caller names by any cell in it -- the walk's current block
+// (px, py, pz) -- and its size exponent `pexp`; the descent starts at the smallest remembered parent that
+// contains both that node and the new cell.
+__device__ __forceinline__ OctCell oct_chunk_near(const DOctNode* nodes, const OctCursor& c, int32_t px, int32_t py, int32_t pz,
+                                                  uint32_t pexp, int32_t x, int32_t y, int32_t z) {
+    const uint32_t diff = (uint32_t)((x ^ px) | (y ^ py) | (z ^ pz));
+    const uint32_t h = 32u - (uint32_t)__clz((int)diff);  // cells agree above bit h - 1 (__clz(0) = 32)
+    uint32_t s = h > pexp + 1 ? h : pexp + 1;             // smallest remembered parent that holds both
     const uint2 e = c.anc[s * c.stride];
     uint32_t link = e.x, kinds = e.y, ci, k;
     for (;;) {
@@ -669,7 +669,6 @@ __device__ __forceinline__ OctCell oct_chunk_near(const DOctNode* nodes, OctCurs
         link = (uint32_t)n.link, kinds = n.kind_size >> 16;
         c.anc[s * c.stride] = uint2{link, kinds};
     }
-    c.x = x, c.y = y, c.z = z, c.leaf_exp = s;
     return OctCell{k, s, link + ci};
 }
 // The same lookup from the root, without a remembered path: trees whose root is not a parent (one node) and
@@ -687,19 +686,18 @@ __device__ OctCell oct_chunk_from_root(const DOctNode* nodes, uint32_t root, uin
         n = oct_node_at(nodes, at);
     }
 }
-// Puts the root on the cursor's remembered path, so that the first lookup of a walk descends from it like any other
-// from its smallest common parent. `cached` (the same for every lane that walks this tree): the tree has a parent
-// root and fits the cursor's array.
-__device__ __forceinline__ bool oct_cursor_start(const DOctNode* nodes, const DOctree& oc, OctCursor& c) {
+// Puts the root on the lane's remembered path, so that the first lookup of a walk (previous node: the whole world,
+// exponent world_log2 - 1 at cell 0) descends from it like any other from its smallest common parent.
+__device__ __forceinline__ void oct_cursor_start(const DOctNode* nodes, const DOctree& oc, const OctCursor& c) {
     const DOctNode n = oct_node_at(nodes, oc.root);
-    const bool cached = (n.kind_size & 0xFF) == MRT_OCT_PARENT && oc.world_log2 < (uint32_t)OCT_ANC_LEVELS;
-    if (cached) c.anc[oc.world_log2 * c.stride] = uint2{(uint32_t)n.link, n.kind_size >> 16};
-    c.x = 0, c.y = 0, c.z = 0, c.leaf_exp = oc.world_log2 - 1, c.valid = cached;
-    return cached;
+    c.anc[oc.world_log2 * c.stride] = uint2{(uint32_t)n.link, n.kind_size >> 16};
 }
+// `CACHED` (the same for every lane that walks this tree, DOctree::cached): the tree has a parent root and fits
+// the remembered path.
 template <bool CACHED>
-__device__ __forceinline__ OctCell oct_lookup(const DOctNode* nodes, const DOctree& oc, OctCursor& c, int32_t x, int32_t y, int32_t z) {
-    if constexpr (CACHED) return oct_chunk_near(nodes, c, x, y, z);
+__device__ __forceinline__ OctCell oct_lookup(const DOctNode* nodes, const DOctree& oc, const OctCursor& c, int32_t px, int32_t py,
+                                              int32_t pz, uint32_t pexp, int32_t x, int32_t y, int32_t z) {
+    if constexpr (CACHED) return oct_chunk_near(nodes, c, px, py, pz, pexp, x, y, z);
     else return oct_chunk_from_root(nodes, oc.root, oc.world_log2, x, y, z);
 }
 // Rust `as i32`: toward zero, saturating, NaN -> 0 -- which is what v_cvt_i32_f64 does by itself
@@ -718,6 +716,7 @@ __device__ __forceinline__ int32_t floor_size(int32_t v, uint32_t s) { return (v
 constexpr int OCT_SUB = 16;
 #ifdef MRT_STAMPS
 // diagnostic build: steps of the octree walk summed over lanes [0], step rounds summed over waves [1]
+// (counted only with -DMRT_OCT_DIAG on top: two atomics per step round distort the cycle stamps)
 __device__ unsigned long long g_oct_diag[2];
 #endif
 constexpr int OCT_EDGE = 6, OCT_VOLUME = 12;
@@ -786,7 +785,7 @@ __device__ __forceinline__ int oct_handle_empty(OctVolume& vs, D3 cur, D3 d, D3&
 template <bool VOL, bool CACHED>
 __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels, const DOctree& oc, int32_t bx, int32_t by,
                                   int32_t bz, D3 origin, D3 d, int initial_normal, const Rng& g, uint32_t& entry, D3& hit_pos,
-                                  int& code, int& voxel, OctCursor& cursor) {
+                                  int& code, int& voxel, const OctCursor& cursor, int32_t qx, int32_t qy, int32_t qz, uint32_t qexp) {
     const uint32_t ws = 1u << oc.world_log2;
     // The node array's address is a field of the scene view in constant memory, which the compiler would rather
     // read again at every lookup than keep: a scalar round trip in front of each step's node load. As an opaque
@@ -796,7 +795,8 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
         return (uint32_t)x < ws && (uint32_t)y < ws && (uint32_t)z < ws;
     };
     if (!in_range(bx, by, bz)) return false;  // get_chunk(..).expect("out of range")
-    const OctCell chunk = oct_lookup<CACHED>(nodes, oc, cursor, bx, by, bz);
+    // (qx, qy, qz, qexp: the node of the lookup before this walk, see oct_chunk_near)
+    const OctCell chunk = oct_lookup<CACHED>(nodes, oc, cursor, qx, qy, qz, qexp, bx, by, bz);
     uint32_t csz = chunk.size;
     bx = floor_size(bx, csz), by = floor_size(by, csz), bz = floor_size(bz, csz);
     D3 cur = origin;
@@ -819,7 +819,7 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
     uint32_t solid_node = ~0u;
     int solid_code = 0;
     for (int it = 0; it < 3000; ++it) {
-#ifdef MRT_STAMPS
+#ifdef MRT_OCT_DIAG
         {
             const unsigned long long act = __ballot(1);
             if ((int)__lane_id() == __ffsll((long long)act) - 1)
@@ -850,7 +850,7 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
         // get_chunk_size panics out of range; this also covers the reference's earlier check of the
         // cell below the old block on the way back (the other two coordinates are the block's own)
         if (!in_range(lx, ly, lz)) break;
-        const OctCell node = oct_lookup<CACHED>(nodes, oc, cursor, lx, ly, lz);
+        const OctCell node = oct_lookup<CACHED>(nodes, oc, cursor, bx, by, bz, csz, lx, ly, lz);
         const uint32_t ncs = node.size;
         const int32_t na = forward ? la : ba - (1 << ncs);
         bx = ax0 ? na : floor_size(cx, ncs);
@@ -871,7 +871,7 @@ __device__ bool oct_ray_iteration(const DOctNode* nodes, const mrt_voxel* voxels
         } else if constexpr (VOL) {
             if (oct_handle_empty(vs, cur, d, hit_pos, code, voxel) == OCT_STOP) return true;
         }
-        step = 1 << ncs;
+        step = 1 << ncs, csz = ncs;
     }
     if (solid_node != ~0u) {
         hit_pos = cur;
@@ -887,8 +887,10 @@ __device__ bool oct_trace_ray(const DOctNode* nodes, const mrt_voxel* voxels, co
                               uint32_t& entry, D3& hit_pos, int& code, int& voxel) {
     const double ws = (double)(1u << oc.world_log2);
     // (the workgroup's dynamic LDS: kernels with octree code are launched with lds_bytes() of it)
-    OctCursor cursor{reinterpret_cast<uint2*>(dynamic_lds()) + threadIdx.x, blockDim.x, 0, 0, 0, 0, false};
+    const OctCursor cursor{reinterpret_cast<uint2*>(dynamic_lds()) + threadIdx.x, blockDim.x};
     if constexpr (CACHED) oct_cursor_start(nodes, oc, cursor);
+    int32_t px = 0, py = 0, pz = 0;         // the node of the previous lookup: a cell in it and its size exponent
+    uint32_t pexp = oc.world_log2 - 1;
     // where the walk starts: at the origin when it lies in the world's cube, else where the ray enters the cube
     D3 position = o;
     int32_t bx = f64_as_i32(o.x), by = f64_as_i32(o.y), bz = f64_as_i32(o.z);
@@ -921,7 +923,8 @@ __device__ bool oct_trace_ray(const DOctNode* nodes, const mrt_voxel* voxels, co
         const int32_t wsi = (int32_t)(1u << oc.world_log2);
         // self.get(block as u32): a negative coordinate wraps and is out of range -> None
         if (bx >= 0 && bx < wsi && by >= 0 && by < wsi && bz >= 0 && bz < wsi) {
-            const OctCell n = oct_lookup<CACHED>(nodes, oc, cursor, bx, by, bz);
+            const OctCell n = oct_lookup<CACHED>(nodes, oc, cursor, px, py, pz, pexp, bx, by, bz);
+            px = bx, py = by, pz = bz, pexp = n.size;
             if (n.kind != MRT_OCT_EMPTY && !(VOL && n.kind == OCT_LEAF_VOLUME)) {  // a solid entry voxel is the hit (ray_trace.rs:653-657)
                 hit_pos = position;
                 code = min_index;  // NORMALS[min_index]: 0 -x, 1 +x, 2 -y, 3 +y, 4 -z, 5 +z
@@ -930,7 +933,8 @@ __device__ bool oct_trace_ray(const DOctNode* nodes, const mrt_voxel* voxels, co
             }
         }
     }
-    return oct_ray_iteration<VOL, CACHED>(nodes, voxels, oc, bx, by, bz, position, d, initial_normal, g, entry, hit_pos, code, voxel, cursor);
+    return oct_ray_iteration<VOL, CACHED>(nodes, voxels, oc, bx, by, bz, position, d, initial_normal, g, entry, hit_pos, code, voxel, cursor,
+                                          px, py, pz, pexp);
 }
 
 // Hittable for FastOctTree<Voxel> (fast_oct_tree/hittable.rs:10-68); `sr` is the object-space ray.
