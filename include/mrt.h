@@ -449,6 +449,10 @@ enum mrt_shader { MRT_SHADER_RAYTRACING = 0, MRT_SHADER_DIFFUSE = 1, MRT_SHADER_
  *                            search, 256..2048 (default 2048). A wave whose queue
  *                            could overflow takes the tree walk for its rays (same
  *                            result); smaller values exist to test that path.
+ *   "octree_suspend"         0/1 (default 1): in scenes whose first object is a solid-voxel octree, the
+ *                            lanes of a wave that are still walking the octree when most others have
+ *                            finished keep their walk for the next turn of the kernel's loop while the
+ *                            others shade and start new paths (same steps, same results)
  *   "trace_zero_throughput"  1: keep walking paths whose throughput is exactly
  *                            zero, as the reference does (same image, counters
  *                            match the reference's)

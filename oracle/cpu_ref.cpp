@@ -182,6 +182,8 @@ struct RngCtx {
     uint64_t rays = 0, light_queries = 0;
 };
 thread_local RngCtx g_rng;
+// Diagnostic: when set, every World::nearest_hit of the calling thread appends the number of octree walk steps it took.
+thread_local std::vector<uint32_t>* g_walk_steps = nullptr;
 
 inline uint64_t rand_u64(uint32_t dim) {
     if (g_rng.mode == 1) return g_rng.mt();
@@ -1053,7 +1055,11 @@ struct World {
         g_rng.medium_ordinal = 0;
         g_rng.oct_ordinal = 0;
         g_rng.in_light_query = false;
-        return root->hit(objects, ray, (double)t_min, (double)t_max);
+        if (!g_walk_steps) return root->hit(objects, ray, (double)t_min, (double)t_max);
+        const unsigned long long before = octref::oct_step_counter();
+        auto rec = root->hit(objects, ray, (double)t_min, (double)t_max);
+        g_walk_steps->push_back((uint32_t)(octref::oct_step_counter() - before));
+        return rec;
     }
     // :98-110; returns the index of the light instead of a clone of it
     std::optional<std::pair<size_t, HitRecord>> nearest_light_hit(const Ray& ray, double t_min, double t_max) const {
@@ -1667,6 +1673,28 @@ int oracle_octree_steps(void* scene, const double* rays, size_t n, uint64_t seed
         (void)s->world.nearest_hit(ray, 0.001f, std::numeric_limits<float>::max());
         steps_out[i] = (uint32_t)(octref::oct_step_counter() - before);
     }
+    return MRT_OK;
+}
+
+// Diagnostic: octree walk steps of every segment of the paths of n pixel-samples (the same paths oracle_sample_radiance
+// traces): steps_out[i * max_segments + k] = steps of segment k of path i, or 0xFFFFFFFF past the path's end.
+int oracle_path_walk_steps(void* scene, uint32_t width, uint32_t height, const int32_t* pixels, size_t n, uint64_t seed,
+                           uint64_t sample_index, uint32_t max_segments, uint32_t* steps_out) {
+    auto* s = static_cast<Scene*>(scene);
+    if (!s || !pixels || !steps_out) return MRT_ERR_INVALID_ARGUMENT;
+    std::vector<uint32_t> rec;
+    g_walk_steps = &rec;
+    for (size_t i = 0; i < n; ++i) {
+        rec.clear();
+        g_rng = RngCtx{};
+        uint32_t x = (uint32_t)pixels[2 * i], y = (uint32_t)pixels[2 * i + 1];
+        g_rng.key = path_key(seed, (uint64_t)x + (uint64_t)y * width, sample_index);
+        double u = ((double)x + rand_scalar(0.0, 1.0, MRT_DIM_JITTER_U)) / ((double)width - 1.0);
+        double v = ((double)y + rand_scalar(0.0, 1.0, MRT_DIM_JITTER_V)) / ((double)height - 1.0);
+        (void)ray_color(s->world.camera->get_ray(u, v), s->world, 50);
+        for (uint32_t k = 0; k < max_segments; ++k) steps_out[i * max_segments + k] = k < rec.size() ? rec[k] : 0xFFFFFFFFu;
+    }
+    g_walk_steps = nullptr;
     return MRT_OK;
 }
 

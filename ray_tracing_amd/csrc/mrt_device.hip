@@ -50,6 +50,8 @@ struct SceneView {
     int32_t n_cand_words;  // 32-node words of the candidate bit array in use
     int32_t n_perlins;
     int32_t cand_queue;    // entries of a wave's search queue in use (CAND_QUEUE; smaller only to test the overflow path)
+    int32_t oct_first;     // 1: the first node the wave-synchronous walk visits is a leaf holding a solid-voxel octree whose walk can be suspended (octree_first_leaf)
+    int32_t pad_view;
     const DCand4* cand_nodes;
     const DObjRec* objects;  // one record per object (shape, transform, material)
     const DObjRec* lights;   // the light list, same record type
@@ -628,6 +630,11 @@ __device__ __forceinline__ uint32_t* dynamic_lds() {
     extern __shared__ uint32_t mrt_dynamic_lds[];
     return mrt_dynamic_lds;
 }
+#ifdef MRT_STAMPS
+// diagnostic build: steps of the octree walk summed over lanes [0], step rounds summed over waves [1]
+// (counted only with -DMRT_OCT_DIAG on top: two atomics per step round distort the cycle stamps)
+__device__ unsigned long long g_oct_diag[6];  // [2] node loads, [3] lane lookups that loaded, [4] wave lookups in which a lane loaded, [5] longest load chains summed over those
+#endif
 struct OctCursor {
     uint2* anc;         // this lane's column of a [OCT_ANC_LEVELS][threads per workgroup] array: (child link, child kinds) of a parent
     uint32_t stride;    // threads per workgroup
@@ -660,6 +667,9 @@ __device__ __forceinline__ OctCell oct_chunk_near(const DOctNode* nodes, const O
     uint32_t s = h > pexp + 1 ? h : pexp + 1;             // smallest remembered parent that holds both
     const uint2 e = c.anc[s * c.stride];
     uint32_t link = e.x, kinds = e.y, ci, k;
+#ifdef MRT_OCT_DIAG
+    uint32_t n_loads = 0;
+#endif
     for (;;) {
         s -= 1;
         ci = ((((uint32_t)x >> s) & 1u) << 2) | ((((uint32_t)y >> s) & 1u) << 1) | (((uint32_t)z >> s) & 1u);
@@ -668,7 +678,23 @@ __device__ __forceinline__ OctCell oct_chunk_near(const DOctNode* nodes, const O
         const DOctNode n = oct_node_at(nodes, link + ci);
         link = (uint32_t)n.link, kinds = n.kind_size >> 16;
         c.anc[s * c.stride] = uint2{link, kinds};
+#ifdef MRT_OCT_DIAG
+        n_loads++;
+#endif
     }
+#ifdef MRT_OCT_DIAG
+    {
+        const unsigned long long act = __ballot(1), ld = __ballot(n_loads > 0);
+        uint32_t mx = n_loads;
+        for (int o = 32; o > 0; o >>= 1) { uint32_t other = (uint32_t)__shfl_xor((int)mx, o, 64); mx = other > mx ? other : mx; }
+        uint32_t total = n_loads;
+        for (int o = 32; o > 0; o >>= 1) total += (uint32_t)__shfl_xor((int)total, o, 64);
+        if ((int)__lane_id() == __ffsll((long long)act) - 1) {
+            atomicAdd(&g_oct_diag[2], (unsigned long long)total), atomicAdd(&g_oct_diag[3], (unsigned long long)__popcll(ld));
+            if (ld) atomicAdd(&g_oct_diag[4], 1ull), atomicAdd(&g_oct_diag[5], (unsigned long long)mx);
+        }
+    }
+#endif
     return OctCell{k, s, link + ci};
 }
 // The same lookup from the root, without a remembered path: trees whose root is not a parent (one node) and
@@ -714,11 +740,6 @@ __device__ __forceinline__ int32_t floor_size(int32_t v, uint32_t s) { return (v
 //   6..11  solid hit by the edge effect of a volume voxel (its solid_material), normal code - 6
 //   12     volume hit: the free path ended inside the volume (material Volume { color }, normal +x)
 constexpr int OCT_SUB = 16;
-#ifdef MRT_STAMPS
-// diagnostic build: steps of the octree walk summed over lanes [0], step rounds summed over waves [1]
-// (counted only with -DMRT_OCT_DIAG on top: two atomics per step round distort the cycle stamps)
-__device__ unsigned long long g_oct_diag[2];
-#endif
 constexpr int OCT_EDGE = 6, OCT_VOLUME = 12;
 
 // RayTraceState::volume_distance_left (ray_trace.rs:93-104)
@@ -958,6 +979,209 @@ __device__ bool octree_hit(const DOctNode* nodes, const mrt_voxel* voxels, const
     sub = voxel * OCT_SUB + code;
     pos_out = hp;
     return true;
+}
+
+// ---- a walk that can be put down and taken up again (solid-voxel trees with a remembered path)
+// In a wave, walks differ in length: in the voxel city a ray takes 12 steps on average and its wave waited 21 rounds for
+// the longest, 36 of 64 lanes stepping. So a walk can stop at a step boundary: when fewer than OCT_SUSPEND_BELOW lanes are
+// still walking (and the others have something to do) those lanes keep their walk -- position, block, its size and
+// the step count in LDS, the remembered path where it is -- while the others shade, start new paths and join them in the
+// next turn of the kernel's loop. The steps a ray takes are the same, one after the other, whatever turn they are taken in.
+struct OctWalk {
+    D3 cur;              // position (ray_iteration's current_position)
+    int32_t bx, by, bz;  // current block
+    uint32_t csz;        // its size exponent
+    int32_t it;          // steps taken (the reference stops at 3000)
+};
+constexpr int OCT_WALK_DWORDS = 11;
+#ifndef MRT_OCT_T
+#define MRT_OCT_T 8
+#endif
+#ifndef MRT_OCT_RMIN
+#define MRT_OCT_RMIN 4
+#endif
+constexpr int OCT_SUSPEND_BELOW = MRT_OCT_T, OCT_SUSPEND_MIN_ROUNDS = MRT_OCT_RMIN;
+enum : int { OCT_WALKING = 0, OCT_MISS = 1, OCT_SOLID = 2, OCT_IDLE = 3 };
+__device__ __forceinline__ uint32_t* oct_walk_lds() {  // this lane's column, behind the remembered paths
+    return dynamic_lds() + 2 * OCT_ANC_LEVELS * blockDim.x + threadIdx.x;
+}
+__device__ __forceinline__ void oct_walk_save(const OctWalk& w) {
+    uint32_t* q = oct_walk_lds();
+    const uint32_t st = blockDim.x;
+    q[0 * st] = (uint32_t)__double2loint(w.cur.x), q[1 * st] = (uint32_t)__double2hiint(w.cur.x);
+    q[2 * st] = (uint32_t)__double2loint(w.cur.y), q[3 * st] = (uint32_t)__double2hiint(w.cur.y);
+    q[4 * st] = (uint32_t)__double2loint(w.cur.z), q[5 * st] = (uint32_t)__double2hiint(w.cur.z);
+    q[6 * st] = (uint32_t)w.bx, q[7 * st] = (uint32_t)w.by, q[8 * st] = (uint32_t)w.bz, q[9 * st] = w.csz, q[10 * st] = (uint32_t)w.it;
+}
+__device__ __forceinline__ OctWalk oct_walk_load() {
+    const uint32_t* q = oct_walk_lds();
+    const uint32_t st = blockDim.x;
+    OctWalk w;
+    w.cur.x = __hiloint2double((int)q[1 * st], (int)q[0 * st]);
+    w.cur.y = __hiloint2double((int)q[3 * st], (int)q[2 * st]);
+    w.cur.z = __hiloint2double((int)q[5 * st], (int)q[4 * st]);
+    w.bx = (int32_t)q[6 * st], w.by = (int32_t)q[7 * st], w.bz = (int32_t)q[8 * st], w.csz = q[9 * st], w.it = (int32_t)q[10 * st];
+    return w;
+}
+// The direction's constants of a walk, worked out where a walk starts or is taken up again.
+struct OctDir {
+    D3 d, inv;
+    bool px, py, pz, fx, fy, fz;  // sign bit clear / component >= 0 (they differ for -0.0)
+};
+__device__ __forceinline__ OctDir oct_dir(D3 d) {
+    return OctDir{d, D3{rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z)}, !__builtin_signbit(d.x), !__builtin_signbit(d.y), !__builtin_signbit(d.z),
+                  d.x >= 0.0, d.y >= 0.0, d.z >= 0.0};
+}
+// One step of ray_iteration (ray_trace.rs:200-470) in a tree of solid voxels: the body of oct_ray_iteration's loop.
+// OCT_SOLID: the step entered a solid leaf, node `solid_node`, normal code `solid_code`, position w.cur.
+__device__ __forceinline__ int oct_step_solid(const DOctNode* nodes, const OctCursor& cursor, uint32_t ws, const OctDir& dr, OctWalk& w,
+                                              uint32_t& solid_node, int& solid_code) {
+    if (w.it >= 3000) return OCT_MISS;  // "Max number of iterations reached"
+    w.it++;
+    const int32_t step = 1 << w.csz;
+    const double tx = ((double)(w.bx + (dr.px ? step : 0)) - w.cur.x) * dr.inv.x;
+    const double ty = ((double)(w.by + (dr.py ? step : 0)) - w.cur.y) * dr.inv.y;
+    const double tz = ((double)(w.bz + (dr.pz ? step : 0)) - w.cur.z) * dr.inv.z;
+    if (tx < 0.0 || ty < 0.0 || tz < 0.0) return OCT_MISS;
+    const bool ax0 = (tx < ty) & (tx < tz), ax1 = !ax0 & (ty < tx) & (ty < tz), ax2 = !ax0 & !ax1;
+    const double txy = vmin_f64(tx, ty);
+    const double tm = ax2 ? tz : txy;
+    const int32_t ba = ax0 ? w.bx : (ax1 ? w.by : w.bz);
+    w.cur.x += tm * dr.d.x, w.cur.y += tm * dr.d.y, w.cur.z += tm * dr.d.z;
+    const int32_t cx = f64_as_i32(w.cur.x), cy = f64_as_i32(w.cur.y), cz = f64_as_i32(w.cur.z);
+    const bool forward = (ax0 && dr.fx) || (ax1 && dr.fy) || (ax2 && dr.fz);
+    const bool plus = (ax0 && dr.px) || (ax1 && dr.py) || (ax2 && dr.pz);
+    const int32_t la = forward ? ba + (plus ? step : -step) : ba - 1;
+    const int32_t lx = ax0 ? la : cx, ly = ax1 ? la : cy, lz = ax2 ? la : cz;
+    if (!((uint32_t)lx < ws && (uint32_t)ly < ws && (uint32_t)lz < ws)) return OCT_MISS;
+    const OctCell node = oct_chunk_near(nodes, cursor, w.bx, w.by, w.bz, w.csz, lx, ly, lz);
+    const uint32_t ncs = node.size;
+    const int32_t na = forward ? la : ba - (1 << ncs);
+    w.bx = ax0 ? na : floor_size(cx, ncs);
+    w.by = ax1 ? na : floor_size(cy, ncs);
+    w.bz = ax2 ? na : floor_size(cz, ncs);
+    w.csz = ncs;
+    if (node.kind != MRT_OCT_EMPTY) {
+        solid_node = node.node;
+        solid_code = (ax0 ? 0 : (ax1 ? 2 : 4)) + (forward ? 0 : 1);
+        return OCT_SOLID;
+    }
+    return OCT_WALKING;
+}
+// trace_ray up to the first step (ray_trace.rs:561-683 and the head of ray_iteration, :472-510), solid voxels.
+__device__ __forceinline__ int oct_walk_begin(const DOctNode* nodes, const DOctree& oc, const OctCursor& cursor, D3 o, D3 d, OctWalk& w,
+                                              uint32_t& solid_node, int& solid_code) {
+    const double ws = (double)(1u << oc.world_log2);
+    const uint32_t wsu = 1u << oc.world_log2;
+    D3 position = o;
+    int32_t bx = f64_as_i32(o.x), by = f64_as_i32(o.y), bz = f64_as_i32(o.z);
+    int32_t qx = 0, qy = 0, qz = 0;
+    uint32_t qexp = oc.world_log2 - 1;
+    if (!(o.x >= 0.0 && o.x <= ws && o.y >= 0.0 && o.y <= ws && o.z >= 0.0 && o.z <= ws)) {
+        double v0 = (0.0 - o.x) / d.x, v1 = (ws - o.x) / d.x;
+        double v2 = (0.0 - o.y) / d.y, v3 = (ws - o.y) / d.y;
+        double v4 = (0.0 - o.z) / d.z, v5 = (ws - o.z) / d.z;
+        int min_x = v0 < v1 ? 0 : 1, min_y = v2 < v3 ? 2 : 3, min_z = v4 < v5 ? 4 : 5;
+        double nx = v0 < v1 ? v0 : v1, fx = v0 < v1 ? v1 : v0;
+        double ny = v2 < v3 ? v2 : v3, fy = v2 < v3 ? v3 : v2;
+        double nz = v4 < v5 ? v4 : v5, fz = v4 < v5 ? v5 : v4;
+        int min_index;
+        double vmin;
+        if (nx > ny && nx > nz) min_index = min_x, vmin = nx;
+        else if (ny > nx && ny > nz) min_index = min_y, vmin = ny;
+        else min_index = min_z, vmin = nz;
+        double vmax;
+        if (fx < fy && fx < fz) vmax = fx;
+        else if (fy < fx && fy < fz) vmax = fy;
+        else vmax = fz;
+        if (!(vmax >= vmin && vmin >= 0.0)) return OCT_MISS;
+        position = o + vmin * d;
+        bx = f64_as_i32(position.x) + (min_index == 1 ? -1 : 0);
+        by = f64_as_i32(position.y) + (min_index == 3 ? -1 : 0);
+        bz = f64_as_i32(position.z) + (min_index == 5 ? -1 : 0);
+        if ((uint32_t)bx < wsu && (uint32_t)by < wsu && (uint32_t)bz < wsu) {
+            const OctCell n = oct_chunk_near(nodes, cursor, qx, qy, qz, qexp, bx, by, bz);
+            qx = bx, qy = by, qz = bz, qexp = n.size;
+            if (n.kind != MRT_OCT_EMPTY) {  // a solid entry voxel is the hit (ray_trace.rs:653-657)
+                w.cur = position;
+                solid_node = n.node, solid_code = min_index;
+                return OCT_SOLID;
+            }
+        }
+    }
+    if (!((uint32_t)bx < wsu && (uint32_t)by < wsu && (uint32_t)bz < wsu)) return OCT_MISS;  // get_chunk(..).expect("out of range")
+    const OctCell chunk = oct_chunk_near(nodes, cursor, qx, qy, qz, qexp, bx, by, bz);
+    w.cur = position;
+    w.csz = chunk.size;
+    w.bx = floor_size(bx, w.csz), w.by = floor_size(by, w.csz), w.bz = floor_size(bz, w.csz);
+    w.it = 0;
+    return OCT_WALKING;  // (a solid starting cell is ignored, ray_trace.rs:476-510)
+}
+// The octree leaf that the wave-synchronous walk visits first (SceneView::oct_first), as Object::hit + Hittable for
+// FastOctTree (hittable.rs:204-237, fast_oct_tree/hittable.rs:10-68) with a walk that can be suspended. `fresh`: lanes
+// that come to the leaf now and passed its box; `resuming`: lanes whose walk was suspended in the kernel loop's previous
+// turn. On return `suspended` marks the lanes whose walk is put down again; the others have their answer in
+// closest / best_*. Every lane of the wave must call this.
+template <class RP>
+__device__ __forceinline__ void octree_first_leaf(SceneRef sv, RP r, int flags, const RayD& ray, D3 inv_world, bool fresh, bool resuming,
+                                                  bool may_suspend, double t_min, double& closest, int& best_obj, int& best_sub,
+                                                  D3& best_pos, bool& suspended) {
+#pragma clang fp contract(off)
+    const DOctNode* nodes = sv.oct_nodes;
+    asm volatile("" : "+s"(nodes));
+    const DOctree& oc = sv.octrees[r->octree];
+    RayD sr = ray;
+    D3 inv = inv_world;
+    if ((flags & NODE_IDENTITY) == 0) {
+        if ((flags & NODE_TRANSLATION) != 0) {
+            sr.o = {ray.o.x + r->to_object.r[0][3], ray.o.y + r->to_object.r[1][3], ray.o.z + r->to_object.r[2][3]};
+        } else {
+            sr = xform_ray(&r->to_object, false, ray);
+            inv = {rcp_fast(sr.d.x), rcp_fast(sr.d.y), rcp_fast(sr.d.z)};
+        }
+    }
+    const OctCursor cursor{reinterpret_cast<uint2*>(dynamic_lds()) + threadIdx.x, blockDim.x};
+    const OctDir dr = oct_dir(normalize(sr.d));
+    const double wsd = (double)(1u << oc.world_log2);
+    OctWalk w{{0.0, 0.0, 0.0}, 0, 0, 0, 0, 0};
+    uint32_t solid_node = ~0u;
+    int solid_code = 0;
+    int status = OCT_IDLE;
+    if (fresh) {
+        status = OCT_MISS;
+        if (oc.n_nodes != 0 && aabb_hit(D3{0.0, 0.0, 0.0}, D3{wsd, wsd, wsd}, sr, inv, t_min, closest)) {
+            oct_cursor_start(nodes, oc, cursor);
+            status = oct_walk_begin(nodes, oc, cursor, sr.o, dr.d, w, solid_node, solid_code);
+        }
+    } else if (resuming) {
+        w = oct_walk_load();
+        status = OCT_WALKING;
+    }
+    const uint32_t ws = 1u << oc.world_log2;
+    for (uint32_t rounds = 0;; ++rounds) {
+        const unsigned long long walking = __ballot(status == OCT_WALKING);
+        if (walking == 0) break;
+        // put the walk down when few lanes are left in it and the others have something to do (a finished query to
+        // shade, or -- the caller's knowledge, in `may_suspend` -- a new path to start); never before every walk has made
+        // OCT_SUSPEND_MIN_ROUNDS steps, so that a walk advances in every turn it is part of
+        if (may_suspend && rounds >= (uint32_t)OCT_SUSPEND_MIN_ROUNDS && __popcll(walking) < OCT_SUSPEND_BELOW) break;
+#ifdef MRT_OCT_DIAG
+        if ((int)__lane_id() == __ffsll((long long)__ballot(1)) - 1)
+            atomicAdd(&g_oct_diag[0], (unsigned long long)__popcll(walking)), atomicAdd(&g_oct_diag[1], 1ull);
+#endif
+        if (status == OCT_WALKING) status = oct_step_solid(nodes, cursor, ws, dr, w, solid_node, solid_code);
+    }
+    suspended = status == OCT_WALKING;
+    if (suspended) oct_walk_save(w);
+    if (status == OCT_SOLID) {
+        const D3 dp = w.cur - sr.o;
+        const double t = sqrt(dot(dp, dp) / dot(sr.d, sr.d));
+        if (t > t_min && t < closest) {  // strict, unlike the other shapes (fast_oct_tree/hittable.rs:28,48)
+            closest = t, best_obj = r->object;
+            best_sub = oct_node_at(nodes, solid_node).link * OCT_SUB + solid_code;
+            best_pos = w.cur;
+        }
+    }
 }
 
 // Object::hit (hittable.rs:204-237) without the material: returns t and the sub-shape id.
@@ -1461,8 +1685,12 @@ __device__ bool nearest_hit_lane(SceneRef sv, const RayD& ray, const Rng& g, boo
 // is a scalar branch. A lane that fails a box test sits out until the walk leaves that subtree
 // (`resume`); a subtree no lane wants is skipped for the whole wave by a ballot. Must be called
 // by every lane of the wave; lanes with live == false only follow along.
+// `walking` (segment kernels of scenes whose first leaf is a solid-voxel octree, SceneView::oct_first): in, the lanes
+// whose octree walk was suspended in the kernel loop's previous turn; out, the lanes whose walk is suspended now and that
+// have no answer yet. `may_suspend`: wave-uniform, the caller has use for the lanes that are not walking.
 template <int FEAT>
-__device__ bool nearest_hit_wave(SceneRef sv, const RayD& ray, const Rng& g, bool live, HitD& out, Stamps& st) {
+__device__ bool nearest_hit_wave(SceneRef sv, const RayD& ray, const Rng& g, bool live, HitD& out, Stamps& st, bool* walking = nullptr,
+                                 bool may_suspend = false) {
     const double t_min = (double)0.001f;
     double closest = (double)FLT_MAX;
     int best_obj = -1, best_sub = 0;
@@ -1473,6 +1701,23 @@ __device__ bool nearest_hit_wave(SceneRef sv, const RayD& ray, const Rng& g, boo
     auto recs = as_const(sv.node_recs);
     int resume = live ? 0 : n;
     int i = 0;
+    if constexpr ((FEAT & FEAT_OCTREE) != 0 && (FEAT & FEAT_VOLUME) == 0) {
+        if (walking != nullptr && sv.oct_first != 0) {
+            // the first node: a leaf with a solid-voxel octree, whose walk can stop between steps
+            auto r = recs;
+            const int flags = r->flags;
+            const bool resuming = live && *walking;
+            const bool fresh = live && !resuming &&
+                               aabb_hit(D3{r->bmin[0], r->bmin[1], r->bmin[2]}, D3{r->bmax[0], r->bmax[1], r->bmax[2]}, ray, inv_d, t_min, closest);
+            bool suspended = false;
+            REGION_BEGIN(leaf0);
+            octree_first_leaf(sv, r, flags, ray, inv_d, fresh, resuming, may_suspend, t_min, closest, best_obj, best_sub, best_pos, suspended);
+            REGION_END(st, ST_LEAF, leaf0);
+            *walking = suspended;
+            if (suspended) resume = n;  // no answer in this turn: the lane sits out the rest of the walk
+            i = 1;
+        }
+    }
     const bool axis_parallel = ray.d.x == 0.0 || ray.d.y == 0.0 || ray.d.z == 0.0;
     // (wave-uniform) the node at hand is a NODE_TWICE node on its second evaluation. The second evaluation is one
     // more turn of this loop on the same node -- box test against the updated bound by the lanes that passed the
@@ -2344,15 +2589,23 @@ __device__ bool shade_finish(SceneRef sv, RayD& ray, F3& thr, const Rng& g, doub
 // One segment for one lane: nearest hit + material response. `live` marks the lanes that carry a
 // path; every lane of the wave must call this (the wave-synchronous traversal and the unit-vector
 // sampler are wave-wide).
+// `walking` / `may_suspend`: see nearest_hit_wave. A lane whose walk is suspended has no answer in this turn: nothing
+// of its path changes, and the caller calls again with `walking` as it came back.
 template <bool WAVE, int FEAT>
 __device__ bool path_segment(SceneRef sv, RayD& ray, F3& thr, const Rng& g, bool live, F3& radiance,
-                             uint32_t& rays, uint32_t& light_queries, Stamps& st, CandLds cand_bits, PerlinLds pl) {
+                             uint32_t& rays, uint32_t& light_queries, Stamps& st, CandLds cand_bits, PerlinLds pl, bool& walking,
+                             bool may_suspend) {
     radiance = {0.f, 0.f, 0.f};
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     bool hit;
     REGION_BEGIN(trav);
     if (WAVE) {
-        hit = nearest_hit_wave<FEAT>(sv, ray, g, live, h, st);
+        if constexpr ((FEAT & FEAT_OCTREE) != 0 && (FEAT & FEAT_VOLUME) == 0) {
+            hit = nearest_hit_wave<FEAT>(sv, ray, g, live, h, st, &walking, may_suspend);
+            live = live && !walking;
+        } else {
+            hit = nearest_hit_wave<FEAT>(sv, ray, g, live, h, st);
+        }
     } else {
         hit = nearest_hit_lane<FEAT>(sv, ray, g, live, h, st, cand_bits);
     }
@@ -2394,7 +2647,7 @@ constexpr int seg_block(bool wave) { return wave ? 64 : 256; }
 // exists, else the candidate-search arrays in the per-lane kernels (trees with octrees do not use
 // the candidate search).
 constexpr size_t lds_bytes(bool wave, int feat, int threads) {
-    if (feat & FEAT_OCTREE) return sizeof(uint2) * OCT_ANC_LEVELS * (size_t)threads;
+    if (feat & FEAT_OCTREE) return (sizeof(uint2) * OCT_ANC_LEVELS + sizeof(uint32_t) * OCT_WALK_DWORDS) * (size_t)threads;
     if (!wave) return sizeof(uint32_t) * (CAND_WORDS + 1) * (size_t)threads + sizeof(uint16_t) * CAND_QUEUE * (size_t)(threads / 64);
     return 0;
 }
@@ -2475,6 +2728,7 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
         }
     }
     uint32_t rays = 0, light_queries = 0;
+    bool walking = false;  // this lane's octree walk was suspended in the previous turn of the loop (nearest_hit_wave)
     uint32_t ended = 0;  // paths of this wave that ended in this launch (wave-uniform: a scalar register)
     // this wave's share of the work range (wave-uniform)
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(slot >> 6);
@@ -2565,11 +2819,17 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
         if (WAVE && !__any(live)) break;
         Rng g{key, (uint32_t)(live ? seg : 0)};
         F3 radiance;
-        bool cont = path_segment<WAVE, FEAT>(sv, ray, thr, g, live, radiance, rays, light_queries, st, cand_bits, perlin_lds);
+        // (an octree walk may be suspended when the lanes that are not walking can do something meanwhile: shade a
+        // finished query, or start a new path; never in a launch's last turn, so that every launch finishes walks --
+        // a walk still suspended when the launch ends starts again from the ray in the next one)
+        const bool may_suspend = step + 1 < steps;
+        bool cont = path_segment<WAVE, FEAT>(sv, ray, thr, g, live, radiance, rays, light_queries, st, cand_bits, perlin_lds, walking,
+                                             may_suspend);
         REGION_BEGIN(acc);
-        if (live && cont && seg >= 49) cont = false;  // depth 50 -> 0 returns BLACK (ray_tracer.rs:166-172, :451)
-        ended += (uint32_t)__popcll(__ballot(live && !cont));
-        if (live) {
+        const bool answered = live && !walking;  // (`walking`: the segment goes on in the next turn, nothing of the path moves)
+        if (answered && cont && seg >= 49) cont = false;  // depth 50 -> 0 returns BLACK (ray_tracer.rs:166-172, :451)
+        ended += (uint32_t)__popcll(__ballot(answered && !cont));
+        if (answered) {
             seg++;
             if (!cont) {
                 // ParallelImagePart::add_xy, parallel_image.rs:328-331
@@ -2896,6 +3156,7 @@ struct mrt_scene {
     int64_t opt_compact = 1;
     int64_t opt_shader = MRT_SHADER_RAYTRACING;
     double paths_per_second = 0.0;  // measured on the scene's latest launch that handed out work
+    int64_t opt_oct_suspend = 1;  // 0: octree walks are never suspended (same results; for comparison)
     int64_t opt_traversal = 0;  // 0 auto, 1 per-lane, 2 wave-synchronous over the tree, 3 over the leaf list, 4 candidates
     const DNodeRec* dev_node_recs = nullptr;
     const DNodeRec* dev_leaf_recs = nullptr;
@@ -2976,12 +3237,24 @@ static int traversal_mode(const mrt_scene* sc) {
 static SceneView view_for(const mrt_scene* sc, int mode) {
     SceneView v = sc->view;
     if (mode != TRAV_CANDIDATES) v.n_cand_nodes = 0, v.n_cand_words = 0;
+    const std::vector<DNodeRec>* recs = &sc->flat.node_recs;
     if (mode == TRAV_WAVE_LEAVES) {
         v.node_recs = sc->dev_leaf_recs;
         v.n_wave_nodes = (int32_t)sc->flat.leaf_recs.size();
+        recs = &sc->flat.leaf_recs;
     } else {
         v.node_recs = sc->dev_node_recs;
         v.n_wave_nodes = (int32_t)sc->flat.node_recs.size();
+    }
+    // the first node of the wave-synchronous walk is a leaf with a solid-voxel octree that keeps a remembered path:
+    // its walk can be suspended (octree_first_leaf). Scenes with volume voxels run kernels without that code.
+    v.oct_first = 0;
+    if ((mode == TRAV_WAVE_LEAVES || mode == TRAV_WAVE_TREE) && !recs->empty() && (sc->features & FEAT_VOLUME) == 0 &&
+        sc->opt_oct_suspend != 0) {
+        const DNodeRec& r0 = (*recs)[0];
+        if (r0.object >= 0 && r0.kind == MRT_SHAPE_OCTREE && (r0.flags & (NODE_TWICE | NODE_DYNAMIC_BOX)) == 0 && r0.octree >= 0 &&
+            (size_t)r0.octree < sc->flat.octrees.size() && sc->flat.octrees[(size_t)r0.octree].cached != 0)
+            v.oct_first = 1;
     }
     return v;
 }
@@ -3300,9 +3573,11 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
                      (double)host.stamp_counts[5] / (double)std::max(1ull, host.stamp_counts[6]),
                      (double)host.stamp_counts[3] / (double)std::max(1ull, host.stamp_counts[6]));
         {
-            unsigned long long od[2] = {0, 0};
+            unsigned long long od[6] = {0, 0, 0, 0, 0, 0};
             (void)hipMemcpyFromSymbol(od, HIP_SYMBOL(g_oct_diag), sizeof(od));
             if (od[1]) std::fprintf(stderr, "[stamps] octree walk: %llu lane steps in %llu wave rounds (all launches so far): %.1f of 64 lanes stepping\n", od[0], od[1], (double)od[0] / (double)od[1]);
+            if (od[1]) std::fprintf(stderr, "[stamps] octree lookups: %llu node loads, %llu lane lookups loaded (%.3f of lane steps), %llu wave lookups loaded (%.3f of rounds), longest chain %.2f loads on average there\n",
+                                    od[2], od[3], (double)od[3] / (double)od[0], od[4], (double)od[4] / (double)od[1], (double)od[5] / (double)std::max(1ull, od[4]));
         }
         std::fprintf(stderr, "[stamps] wave-cycles per region (share of total, active lanes of 64)\n");
         for (int i = 0; i < ST_COUNT; ++i)
@@ -3627,6 +3902,11 @@ int mrt_scene_set_option(mrt_scene* scene, const char* name, int64_t value) {
     } else if (n == "traversal") {
         if (value < 0 || value > 4) return set_error(MRT_ERR_INVALID_ARGUMENT, "traversal must be 0..4");
         scene->opt_traversal = value;
+    } else if (n == "octree_suspend") {
+        scene->opt_oct_suspend = value ? 1 : 0;
+        if (scene->device < 0) return MRT_OK;
+        HIP_TRY(hipSetDevice(scene->device));
+        return upload_views(scene);
     } else if (n == "candidate_queue") {
         if (value < 256 || value > CAND_QUEUE) return set_error(MRT_ERR_INVALID_ARGUMENT, "candidate_queue must be 256..2048");
         if (scene->device < 0) return set_error(MRT_ERR_INVALID_ARGUMENT, "scene has no device image");
