@@ -223,7 +223,15 @@ def test_rays_at_rectangle_borders(worlds, name):
     assert np.array_equal(tg[same_walk], tl[same_walk], equal_nan=True)  # (a ray lying in a rectangle's plane "hits" it at t = 0 * inf)
     oo, to, no, po, fo = ow.trace_rays(rays, seed=9)
     mism = og != oo
-    assert mism.sum() <= 0.25 * len(rays)
+    # Measured (tests/border_rates.py -> profiles/r03_border_rates.json): of these rays, every one aimed exactly at a
+    # border, the device and the checker disagree on 20.2 % (Cornell Smoke), 23.6 % (Easy Cornell Box), 9.6 % (Easy
+    # Scene), 9.9 % (Light Demonstration), 9.5 % (Two Sphere); half of the Cornell disagreements are two surfaces at
+    # the same t, a third a hit against a miss. The bound is the measured rate and a quarter. (With the rectangle's
+    # t as the correctly rounded quotient and unfused in-plane coordinates the Cornell rate halves, to 10 %, for
+    # 6.8 % of the headline kernel's speed -- measured, not kept.)
+    bound = {"Cornell Smoke": 0.26, "Easy Cornell Box": 0.30, "Easy Scene": 0.125, "Light Demonstration": 0.125, "Two Sphere": 0.12}[name]
+    print(f"{name}: border rays {len(rays)}, id mismatch against the checker {mism.mean():.4f} (bound {bound}), walks differ {int(walk_mism.sum())}")
+    assert mism.mean() <= bound
     # (a medium's t hangs on the number of medium visits before it -- the draws are numbered by visit -- so one
     # border decision the other way moves it: compared for solid objects only)
     from ray_tracing_amd.scene import ConstantMedium
@@ -344,6 +352,24 @@ def test_scheduling_options_do_not_change_results(opts):
     img, st = gpu_render(rt, 80, 45, 6)
     assert st.rays == rst.rays and st.light_queries == rst.light_queries
     np.testing.assert_allclose(img, ref, rtol=1e-5, atol=1e-6)   # f32 atomic adds: order-dependent last bits
+
+
+@pytest.mark.parametrize("name", ["Voxel City", "Fast Oct Tree Sinnoh", "Fast Oct Tree Sphere"])
+def test_suspended_octree_walks_do_not_change_results(name):
+    """Lanes whose octree walk outlasts most of their wave keep it for the next turn of the kernel loop ("octree_suspend",
+    on by default). A ray takes the same steps whatever turn they are taken in: same counters, same image as with whole
+    walks -- also when launches are so short (2 or 3 turns) that walks are put down at a launch's end and start again."""
+    info = scene_by_name(name)
+    whole = RayTracer(info, device=0, seed=12)
+    whole.world.set_option("octree_suspend", 0)
+    ref, rst = gpu_render(whole, 160, 90, 6)
+    for opts in (dict(), dict(segments_per_launch=2), dict(segments_per_launch=3, pool_slots=4096)):
+        rt = RayTracer(info, device=0, seed=12)
+        for k, v in opts.items():
+            rt.world.set_option(k, v)
+        img, st = gpu_render(rt, 160, 90, 6)
+        assert st.rays == rst.rays and st.light_queries == rst.light_queries and st.paths == rst.paths
+        np.testing.assert_allclose(img, ref, rtol=1e-5, atol=1e-6)   # f32 atomic adds: order-dependent last bits
 
 
 def test_strips_and_sample_ranges_compose(worlds):
