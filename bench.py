@@ -449,6 +449,13 @@ def main():
             prof = committed_profile(profile_key)
             if prof:
                 roof["counters_from"] = prof["file"]
+                # the counters describe the kernels as they were when the profile was taken
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                    from pmc_traffic import kernel_sources_sha256
+                    roof["counters_match_current_sources"] = prof.get("kernel_sources_sha256") == kernel_sources_sha256()
+                except (ImportError, OSError):
+                    roof["counters_match_current_sources"] = None
                 prof_launches_per_step = prof.get("bench_line_under_trace", {}).get("roofline", {}).get("launches", 0) / \
                     max(1, prof.get("bench_line_under_trace", {}).get("steps", 1))
                 same_launches = abs(prof_launches_per_step - totals["launches"] / max(1, args.steps)) <= 1

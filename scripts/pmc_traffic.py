@@ -27,9 +27,21 @@ def counters(pattern):
     return agg, {k: len(v) for k, v in disp.items()}
 
 
+def kernel_sources_sha256():
+    """Digest of the library's sources: a bench line that quotes these counters says whether the kernels have changed since."""
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("mrt_device.hip", "mrt_post.hip", "mrt_host.cpp", "mrt_octree.cpp", "mrt_internal.h"):
+        h.update(open(os.path.join(root, "ray_tracing_amd", "csrc", f), "rb").read())
+    h.update(open(os.path.join(root, "Makefile"), "rb").read())
+    return h.hexdigest()
+
+
 def main():
     root, out = sys.argv[1], sys.argv[2]
-    res = {"source": root, "kernel": None}
+    res = {"source": root, "kernel": None, "kernel_sources_sha256": kernel_sources_sha256()}
     stats = glob.glob(f"{root}/trace/*/*_kernel_stats.csv")
     if stats:
         for r in csv.DictReader(open(stats[0])):

@@ -131,3 +131,23 @@ def test_bench_ends_quickly_when_one_rank_dies():
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]     # no result line from a failed run
     with open(os.path.join(root, "gpurun_out", "rank1.err")) as f:
         assert "MRT_BENCH_FAIL_RANK" in f.read()
+
+
+def test_bench_as_ranks_of_torch_distributed_run():
+    """The other way the benchmark is started for N > 1: `python -m torch.distributed.run ... bench.py --gpus N`, one
+    process per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment (rehearsed with gloo, no GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--backend", "gloo", "--dry", "--width", "32", "--height", "16", "--spp", "4"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout                 # rank 0 alone prints the line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["collective"]["world_size"] == 2 and out["collective"]["ranks_seen"] == [0, 1]
+    assert out["mean_radiance"] == 1.0
