@@ -350,6 +350,7 @@ __device__ __forceinline__ uint32_t rand_u32(const Rng& g, uint32_t mn, uint32_t
 // (u0, u1): the first two uniforms of the first candidate when the caller has drawn them already
 // (dimensions base and base + 1), else negative.
 __device__ D3 rand_unit_vec(const Rng& g, uint32_t base, double u0 = -1.0, double u1 = -1.0) {
+#pragma nounroll
     for (uint32_t k = 0; k < MRT_MAX_REJECT; ++k) {
         const bool pre = k == 0 && u0 >= 0.0;
         D3 rv{pre ? u0 : rng_f64(g, base + 3 * k), pre ? u1 : rng_f64(g, base + 3 * k + 1), rng_f64(g, base + 3 * k + 2)};
@@ -366,11 +367,32 @@ __device__ D3 rand_unit_vec(const Rng& g, uint32_t base, double u0 = -1.0, doubl
 // request takes the first attempt of its group that lands in the ball, and requests whose group failed go
 // round again with the next attempts. Same vector as rand_unit_vec, bit for bit. Every lane of the wave
 // must call this together.
-__device__ D3 wave_rand_unit_vec(bool want, uint64_t rng_base, uint32_t dim_base) {
+// DIMS = 3: the unit ball (rand_unit_vec). DIMS = 2: the unit disk of the camera's lens (random_in_unit_disk,
+// camera.rs:99-106: rand_scalar(-1, 1) twice per attempt, z = 0), attempt k at dimensions dim_base + 2k, + 1.
+template <int DIMS>
+__device__ D3 wave_rand_reject(bool want, uint64_t rng_base, uint32_t dim_base) {
     D3 out{0.0, 0.0, 0.0};
     const uint32_t lane = __lane_id();
     uint32_t first = 0;  // attempts of this lane's request that have failed
     unsigned long long mask = __ballot(want);
+    if (__popcll(mask) > 32) {
+        // more than half of the lanes ask: a round of the scheme below would give every request one attempt, made by
+        // some other lane; each asking lane makes its own first attempt instead, with nothing to carry between lanes
+        const uint64_t at = rng_base + 0x9E3779B97F4A7C15ULL * (uint64_t)(dim_base + 1u);
+        D3 v;
+        if constexpr (DIMS == 3) {
+            D3 rv{(double)(mix64(at) >> 11) * 0x1.0p-53, (double)(mix64(at + 0x9E3779B97F4A7C15ULL) >> 11) * 0x1.0p-53,
+                  (double)(mix64(at + 2u * 0x9E3779B97F4A7C15ULL) >> 11) * 0x1.0p-53};
+            v = 2.0 * (rv - D3{0.5, 0.5, 0.5});
+        } else {
+            v = D3{fma((double)(mix64(at) >> 11) * 0x1.0p-53, 2.0, -1.0), fma((double)(mix64(at + 0x9E3779B97F4A7C15ULL) >> 11) * 0x1.0p-53, 2.0, -1.0), 0.0};
+        }
+        if (want) {
+            if (dot(v, v) < 1.0) out = v, want = false;
+            else first = 1;
+        }
+        mask = __ballot(want);
+    }
     while (mask != 0) {
         const uint32_t n = (uint32_t)__popcll(mask);
         const uint32_t log_a = n > 32 ? 0u : (n > 16 ? 1u : (n > 8 ? 2u : 3u));  // attempts per request this round
@@ -386,11 +408,21 @@ __device__ D3 wave_rand_unit_vec(bool want, uint64_t rng_base, uint32_t dim_base
         const uint32_t r_dim = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)dim_base);
         const uint32_t r_first = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)first);
         const uint32_t attempt = r_first + a;
-        const uint64_t at = (((uint64_t)b_hi << 32) | b_lo) + 0x9E3779B97F4A7C15ULL * (uint64_t)(r_dim + 3u * attempt + 1u);
-        D3 rv{(double)(mix64(at) >> 11) * 0x1.0p-53, (double)(mix64(at + 0x9E3779B97F4A7C15ULL) >> 11) * 0x1.0p-53,
-              (double)(mix64(at + 2u * 0x9E3779B97F4A7C15ULL) >> 11) * 0x1.0p-53};
-        D3 v = 2.0 * (rv - D3{0.5, 0.5, 0.5});
-        const bool ok = q < n && attempt < MRT_MAX_REJECT && dot(v, v) < 1.0;
+        const uint64_t at = (((uint64_t)b_hi << 32) | b_lo) + 0x9E3779B97F4A7C15ULL * (uint64_t)(r_dim + (uint32_t)DIMS * attempt + 1u);
+        D3 v;
+        bool inside;
+        if constexpr (DIMS == 3) {
+            D3 rv{(double)(mix64(at) >> 11) * 0x1.0p-53, (double)(mix64(at + 0x9E3779B97F4A7C15ULL) >> 11) * 0x1.0p-53,
+                  (double)(mix64(at + 2u * 0x9E3779B97F4A7C15ULL) >> 11) * 0x1.0p-53};
+            v = 2.0 * (rv - D3{0.5, 0.5, 0.5});
+            inside = dot(v, v) < 1.0;
+        } else {
+            // rand_scalar(-1, 1) = u * 2 + (-1) (exact either way: u has 53 bits); the test as the per-lane sampler's
+            // code makes it, camera_ray
+            v = D3{fma((double)(mix64(at) >> 11) * 0x1.0p-53, 2.0, -1.0), fma((double)(mix64(at + 0x9E3779B97F4A7C15ULL) >> 11) * 0x1.0p-53, 2.0, -1.0), 0.0};
+            inside = dot(v, v) < 1.0;
+        }
+        const bool ok = q < n && attempt < MRT_MAX_REJECT && inside;
         const unsigned long long accepted = __ballot(ok);
         // (a lane without a request can have rank == n, i.e. a shift by 64: masked, its value is not used)
         const uint32_t mine = (uint32_t)(accepted >> ((rank << log_a) & 63u)) & ((1u << (1u << log_a)) - 1u);
@@ -399,7 +431,9 @@ __device__ D3 wave_rand_unit_vec(bool want, uint64_t rng_base, uint32_t dim_base
         D3 got;
         got.x = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(v.x)), __builtin_amdgcn_ds_bpermute(sel, __double2loint(v.x)));
         got.y = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(v.y)), __builtin_amdgcn_ds_bpermute(sel, __double2loint(v.y)));
-        got.z = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(v.z)), __builtin_amdgcn_ds_bpermute(sel, __double2loint(v.z)));
+        got.z = 0.0;
+        if constexpr (DIMS == 3)
+            got.z = __hiloint2double(__builtin_amdgcn_ds_bpermute(sel, __double2hiint(v.z)), __builtin_amdgcn_ds_bpermute(sel, __double2loint(v.z)));
         if (found) {
             out = got;
             want = false;
@@ -410,6 +444,9 @@ __device__ D3 wave_rand_unit_vec(bool want, uint64_t rng_base, uint32_t dim_base
         mask = __ballot(want);
     }
     return out;
+}
+__device__ __forceinline__ D3 wave_rand_unit_vec(bool want, uint64_t rng_base, uint32_t dim_base) {
+    return wave_rand_reject<3>(want, rng_base, dim_base);
 }
 
 // Scene records are read through two kinds of pointers: ordinary global pointers when the
@@ -2383,19 +2420,38 @@ __host__ __device__ inline double reciprocal_for_div_by(double d) {
     return (d >= 1.0 && d <= 1e15) ? 1.0 / d : __builtin_nan("");
 }
 // `inv_w1`, `inv_h1`: reciprocal_for_div_by(width - 1), (height - 1)
-__device__ RayD camera_ray(SceneRef sv, uint32_t x, uint32_t y, uint32_t width, uint32_t height,
-                           const Rng& g, double inv_w1, double inv_h1) {
+// Camera::get_ray (camera.rs:88-98) without the lens sample: the ray through the lens centre.
+__device__ __forceinline__ RayD camera_ray_pinhole(SceneRef sv, uint32_t x, uint32_t y, uint32_t width, uint32_t height,
+                                                   const Rng& g, double inv_w1, double inv_h1) {
     const auto& c = sv.cam;
     double s = div_by((double)x + rand_scalar(g, 0.0, 1.0, MRT_DIM_JITTER_U), (double)width - 1.0, inv_w1);
     double t = div_by((double)y + rand_scalar(g, 0.0, 1.0, MRT_DIM_JITTER_V), (double)height - 1.0, inv_h1);
     RayD r;
     r.o = ld3(c.origin);
     r.d = ld3(c.lower_left_corner) + s * ld3(c.horizontal) + t * ld3(c.vertical) - ld3(c.origin);
-    // rand_in_unit_disk (camera.rs:91). With a zero lens radius the sample is multiplied by 0, the offset is a
+    // rand_scalar(start, end) is start + u * 0 when the shutter interval is empty
+    r.time = c.start_time == c.end_time ? c.start_time : rand_scalar(g, c.start_time, c.end_time, MRT_DIM_TIME);
+    return r;
+}
+// The lens sample `p` (a point in the unit disk) moves the direction: rd = lens_radius * p, offset = u * rd.x + v * rd.y,
+// direction - offset (camera.rs:91-96; the origin stays the camera's).
+__device__ __forceinline__ void camera_lens(SceneRef sv, D3 p, RayD& r) {
+    const auto& c = sv.cam;
+    D3 rd = c.lens_radius * p;
+    D3 offset = ld3(c.u) * rd.x + ld3(c.v) * rd.y;
+    r.d = r.d - offset;
+}
+// The whole of get_ray for one lane (the probes and the single-bounce shaders; the segment kernel samples the
+// lens for all its lanes at once, wave_rand_reject<2>).
+__device__ RayD camera_ray(SceneRef sv, uint32_t x, uint32_t y, uint32_t width, uint32_t height,
+                           const Rng& g, double inv_w1, double inv_h1) {
+    RayD r = camera_ray_pinhole(sv, x, y, width, height, g, inv_w1, inv_h1);
+    // rand_in_unit_disk (camera.rs:99-106). With a zero lens radius the sample is multiplied by 0, the offset is a
     // zero vector and subtracting it changes nothing; the draws are addressed by dimension, so skipping them
     // changes nothing else.
-    if (c.lens_radius != 0.0) {
+    if (sv.cam.lens_radius != 0.0) {
         D3 p{0.0, 0.0, 0.0};
+#pragma nounroll
         for (uint32_t k = 0; k < MRT_MAX_REJECT; ++k) {
             D3 q{rand_scalar(g, -1.0, 1.0, MRT_DIM_LENS + 2 * k), rand_scalar(g, -1.0, 1.0, MRT_DIM_LENS + 2 * k + 1), 0.0};
             if (dot(q, q) < 1.0) {
@@ -2403,12 +2459,8 @@ __device__ RayD camera_ray(SceneRef sv, uint32_t x, uint32_t y, uint32_t width, 
                 break;
             }
         }
-        D3 rd = c.lens_radius * p;
-        D3 offset = ld3(c.u) * rd.x + ld3(c.v) * rd.y;
-        r.d = r.d - offset;
+        camera_lens(sv, p, r);
     }
-    // rand_scalar(start, end) is start + u * 0 when the shutter interval is empty
-    r.time = c.start_time == c.end_time ? c.start_time : rand_scalar(g, c.start_time, c.end_time, MRT_DIM_TIME);
     return r;
 }
 
@@ -2801,6 +2853,7 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
                 chunk_next = nb + taken;
                 chunk_end = ne;
             }
+            bool fresh = false;  // lanes that start a path in this turn
             if (want && w != ~0ULL) {
                 uint32_t sample, pl, y, xs;
                 divmod_u32(w, (uint32_t)rp.npix_strip, rp.inv_npix_strip, sample, pl);
@@ -2809,9 +2862,16 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
                 pixel = x + y * rp.width;
                 key = path_key(rp.seed, (uint64_t)pixel, rp.first_sample + sample);
                 Rng g{key, 0};
-                ray = camera_ray(sv, x, y, rp.width, rp.height, g, rp.inv_w1, rp.inv_h1);
+                ray = camera_ray_pinhole(sv, x, y, rp.width, rp.height, g, rp.inv_w1, rp.inv_h1);
                 thr = {1.f, 1.f, 1.f};
                 seg = 0;
+                fresh = true;
+            }
+            // The lens sample of the new paths, by the whole wave: a rejection loop per lane kept the wave for its
+            // unluckiest lane (3.4 attempts of two draws with forty lanes asking; 10 % of the headline kernel).
+            if (sv.cam.lens_radius != 0.0) {
+                const D3 lens = wave_rand_reject<2>(fresh, key, MRT_DIM_LENS);
+                if (fresh) camera_lens(sv, lens, ray);
             }
         }
         REGION_END(st, ST_REGEN, regen);
@@ -3017,11 +3077,23 @@ __global__ void __launch_bounds__(BLOCK) k_camera_rays(const SceneView* svp, uin
                                                        const int32_t* pixels, uint32_t n, uint64_t seed,
                                                        uint64_t sample, double* out) {
     SceneRef sv = *as_const(svp);
+    // (the segment kernel's way: the pinhole ray per lane, the lens sample by the whole wave -- odd lanes; the even
+    // lanes take the one-lane form the single-bounce shaders use, so that the probe checks both)
     uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    uint32_t x = (uint32_t)pixels[2 * i], y = (uint32_t)pixels[2 * i + 1];
-    Rng g{path_key(seed, (uint64_t)x + (uint64_t)y * width, sample), 0};
-    RayD r = camera_ray(sv, x, y, width, height, g, reciprocal_for_div_by((double)width - 1.0), reciprocal_for_div_by((double)height - 1.0));
+    const bool live = i < n;
+    uint32_t x = 0, y = 0;
+    if (live) x = (uint32_t)pixels[2 * i], y = (uint32_t)pixels[2 * i + 1];
+    const uint64_t key = path_key(seed, (uint64_t)x + (uint64_t)y * width, sample);
+    Rng g{key, 0};
+    const double inv_w1 = reciprocal_for_div_by((double)width - 1.0), inv_h1 = reciprocal_for_div_by((double)height - 1.0);
+    const bool by_wave = (i & 1u) != 0;
+    RayD r = camera_ray_pinhole(sv, x, y, width, height, g, inv_w1, inv_h1);
+    if (sv.cam.lens_radius != 0.0) {
+        const D3 lens = wave_rand_reject<2>(live && by_wave, key, MRT_DIM_LENS);
+        if (live && by_wave) camera_lens(sv, lens, r);
+    }
+    if (live && !by_wave) r = camera_ray(sv, x, y, width, height, g, inv_w1, inv_h1);
+    if (!live) return;
     double* o = out + 7 * (size_t)i;
     o[0] = r.o.x, o[1] = r.o.y, o[2] = r.o.z, o[3] = r.d.x, o[4] = r.d.y, o[5] = r.d.z, o[6] = r.time;
 }
