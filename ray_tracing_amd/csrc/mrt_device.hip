@@ -238,6 +238,18 @@ __device__ __forceinline__ double div_by_reciprocal(double a, double d, double i
     const double q1 = fma(fma(-d, q0, a), inv, q0);
     return fma(fma(-d, q1, a), inv, q1);
 }
+// a / d for any finite a from inv = rcp_fast(d) (within an ulp of 1 / d): the product and two corrections by the exact
+// residual. The first leaves a faithful quotient, the second the correctly rounded one unless a / d lies within
+// 2^-52 ulp of a rounding boundary, which a quotient of two doubles comes to with a probability of that order. A zero
+// divisor (inv infinite) keeps the product, the IEEE quotient there (+-inf, or NaN for 0 / 0), of which the corrections
+// would make NaN. Eight instructions for the thirty of the division.
+__device__ __forceinline__ double div_by_rcp(double a, double d, double inv) {
+#pragma clang fp contract(off)
+    const double q0 = a * inv;
+    const double q1 = fma(fma(-d, q0, a), inv, q0);
+    const double q2 = fma(fma(-d, q1, a), inv, q1);
+    return q2 == q2 ? q2 : q0;
+}
 // 1/sqrt(x) from v_rsq_f64 plus two Newton steps, for x > 0 finite.
 __device__ __forceinline__ double rsqrt_fast(double x) {
     double y = __builtin_amdgcn_rsq(x);
@@ -709,7 +721,9 @@ __device__ __forceinline__ OctCell oct_chunk_near(const DOctNode* nodes, const O
 #endif
     for (;;) {
         s -= 1;
-        ci = ((((uint32_t)x >> s) & 1u) << 2) | ((((uint32_t)y >> s) & 1u) << 1) | (((uint32_t)z >> s) & 1u);
+        // (bit s of each coordinate by the bit-field instruction: five instructions for the eight of shifts and masks)
+        ci = (__builtin_amdgcn_ubfe((uint32_t)x, s, 1u) << 2) | (__builtin_amdgcn_ubfe((uint32_t)y, s, 1u) << 1) |
+             __builtin_amdgcn_ubfe((uint32_t)z, s, 1u);
         k = (kinds >> (2u * ci)) & 3u;
         if (k != MRT_OCT_PARENT) break;
         const DOctNode n = oct_node_at(nodes, link + ci);
@@ -954,9 +968,11 @@ __device__ bool oct_trace_ray(const DOctNode* nodes, const mrt_voxel* voxels, co
     int32_t bx = f64_as_i32(o.x), by = f64_as_i32(o.y), bz = f64_as_i32(o.z);
     int initial_normal = 1;  // unit_x
     if (!(o.x >= 0.0 && o.x <= ws && o.y >= 0.0 && o.y <= ws && o.z >= 0.0 && o.z <= ws)) {
-        double v0 = (0.0 - o.x) / d.x, v1 = (ws - o.x) / d.x;
-        double v2 = (0.0 - o.y) / d.y, v3 = (ws - o.y) / d.y;
-        double v4 = (0.0 - o.z) / d.z, v5 = (ws - o.z) / d.z;
+        // (the six quotients of ray_trace.rs:575-600 by the direction's reciprocals, div_by_rcp)
+        const D3 id{rcp_fast(d.x), rcp_fast(d.y), rcp_fast(d.z)};
+        double v0 = div_by_rcp(0.0 - o.x, d.x, id.x), v1 = div_by_rcp(ws - o.x, d.x, id.x);
+        double v2 = div_by_rcp(0.0 - o.y, d.y, id.y), v3 = div_by_rcp(ws - o.y, d.y, id.y);
+        double v4 = div_by_rcp(0.0 - o.z, d.z, id.z), v5 = div_by_rcp(ws - o.z, d.z, id.z);
         // entry = the largest of the per-axis near planes, exit = the smallest of the far planes
         int min_x = v0 < v1 ? 0 : 1, min_y = v2 < v3 ? 2 : 3, min_z = v4 < v5 ? 4 : 5;
         double nx = v0 < v1 ? v0 : v1, fx = v0 < v1 ? v1 : v0;
@@ -1106,8 +1122,9 @@ __device__ __forceinline__ int oct_step_solid(const DOctNode* nodes, const OctCu
     return OCT_WALKING;
 }
 // trace_ray up to the first step (ray_trace.rs:561-683 and the head of ray_iteration, :472-510), solid voxels.
-__device__ __forceinline__ int oct_walk_begin(const DOctNode* nodes, const DOctree& oc, const OctCursor& cursor, D3 o, D3 d, OctWalk& w,
+__device__ __forceinline__ int oct_walk_begin(const DOctNode* nodes, const DOctree& oc, const OctCursor& cursor, D3 o, const OctDir& dr, OctWalk& w,
                                               uint32_t& solid_node, int& solid_code) {
+    const D3 d = dr.d;
     const double ws = (double)(1u << oc.world_log2);
     const uint32_t wsu = 1u << oc.world_log2;
     D3 position = o;
@@ -1115,9 +1132,10 @@ __device__ __forceinline__ int oct_walk_begin(const DOctNode* nodes, const DOctr
     int32_t qx = 0, qy = 0, qz = 0;
     uint32_t qexp = oc.world_log2 - 1;
     if (!(o.x >= 0.0 && o.x <= ws && o.y >= 0.0 && o.y <= ws && o.z >= 0.0 && o.z <= ws)) {
-        double v0 = (0.0 - o.x) / d.x, v1 = (ws - o.x) / d.x;
-        double v2 = (0.0 - o.y) / d.y, v3 = (ws - o.y) / d.y;
-        double v4 = (0.0 - o.z) / d.z, v5 = (ws - o.z) / d.z;
+        // (the six quotients of ray_trace.rs:575-600 by the direction's reciprocals, div_by_rcp)
+        double v0 = div_by_rcp(0.0 - o.x, d.x, dr.inv.x), v1 = div_by_rcp(ws - o.x, d.x, dr.inv.x);
+        double v2 = div_by_rcp(0.0 - o.y, d.y, dr.inv.y), v3 = div_by_rcp(ws - o.y, d.y, dr.inv.y);
+        double v4 = div_by_rcp(0.0 - o.z, d.z, dr.inv.z), v5 = div_by_rcp(ws - o.z, d.z, dr.inv.z);
         int min_x = v0 < v1 ? 0 : 1, min_y = v2 < v3 ? 2 : 3, min_z = v4 < v5 ? 4 : 5;
         double nx = v0 < v1 ? v0 : v1, fx = v0 < v1 ? v1 : v0;
         double ny = v2 < v3 ? v2 : v3, fy = v2 < v3 ? v3 : v2;
@@ -1177,7 +1195,10 @@ __device__ __forceinline__ void octree_first_leaf(SceneRef sv, RP r, int flags, 
             inv = {rcp_fast(sr.d.x), rcp_fast(sr.d.y), rcp_fast(sr.d.z)};
         }
     }
-    const OctCursor cursor{reinterpret_cast<uint2*>(dynamic_lds()) + threadIdx.x, blockDim.x};
+    // (only the segment kernels of the wave-synchronous walk come here, single-wave workgroups: the stride of the
+    // per-lane LDS arrays is a constant, and a level's address a shift instead of a multiplication)
+    constexpr uint32_t WG = 64;
+    const OctCursor cursor{reinterpret_cast<uint2*>(dynamic_lds()) + threadIdx.x, WG};
     const OctDir dr = oct_dir(normalize(sr.d));
     const double wsd = (double)(1u << oc.world_log2);
     OctWalk w{{0.0, 0.0, 0.0}, 0, 0, 0, 0, 0};
@@ -1188,7 +1209,7 @@ __device__ __forceinline__ void octree_first_leaf(SceneRef sv, RP r, int flags, 
         status = OCT_MISS;
         if (oc.n_nodes != 0 && aabb_hit(D3{0.0, 0.0, 0.0}, D3{wsd, wsd, wsd}, sr, inv, t_min, closest)) {
             oct_cursor_start(nodes, oc, cursor);
-            status = oct_walk_begin(nodes, oc, cursor, sr.o, dr.d, w, solid_node, solid_code);
+            status = oct_walk_begin(nodes, oc, cursor, sr.o, dr, w, solid_node, solid_code);
         }
     } else if (resuming) {
         w = oct_walk_load();
@@ -2695,6 +2716,7 @@ __device__ __forceinline__ CandLds candidate_lds(SceneRef sv) {
 // +4 % on Cornell smoke, +8 % on the voxel city over 256), 256 for the per-lane kernels (measured
 // better with the candidate search's LDS traffic).
 constexpr int seg_block(bool wave) { return wave ? 64 : 256; }
+static_assert(seg_block(true) == 64, "octree_first_leaf takes the wave-synchronous kernels' workgroup for 64 threads");
 // Dynamic LDS a kernel of `threads` threads needs: the octree ancestor cache where octree code
 // exists, else the candidate-search arrays in the per-lane kernels (trees with octrees do not use
 // the candidate search).
