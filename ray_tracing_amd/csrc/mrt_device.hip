@@ -1488,11 +1488,35 @@ __device__ __forceinline__ bool lane_visit(SceneRef sv, const DNode& nd, const D
     }
     return true;
 }
-// Per-ray constants of the candidate search's slab tests: t = bound * inv - origin * inv.
+// Per-ray constants of the candidate search's slab tests, t = bound * inv - origin * inv, in single precision.
+// The search only has to mark a SUPERSET of the leaves the ray's line meets (every marked leaf is tested again
+// with the walk's own arithmetic), so its slab tests run in f32 -- half the lane reads, no conversions of the f32
+// boxes, two slabs per instruction -- and every slab interval is widened by a bound on what f32 rounds away. With
+// u = 2^-24, B the largest |bound| of the node's children on the axis and V their largest |velocity bound|: a
+// child bound at the ray's time (tau rounded, the product rounded, the sum rounded) is within u (B + 3 |tau| V) of
+// its exact value, inv and origin * inv within u of theirs, and the fused t rounds once more, so
+// |t32 - t| <= 3 u S (1 + small) with S = (B + 3 |tau| V) |inv| + |origin * inv|; widening by CAND_SLACK * S leaves
+// 1.5 u S for the rounding of S itself and of the widened ends. (The slack matters: a bounced ray starts ON a
+// sphere, whose slab interval ends at t = 0 just below the query's 0.001; one slack for the whole tree -- its
+// largest bound is the ground sphere's 2000 -- marked that sphere for most rays, 12 % of the kernel.)
+constexpr float CAND_SLACK = 4.5f * 0x1p-24f;
 struct CandRay {
-    double inv[3], oi[3];
-    double tau;  // the ray's time
+    float inv[3], oi[3];
+    float tau;  // the ray's time
 };
+typedef float v4f __attribute__((ext_vector_type(4)));
+// The constants of a ray for the search; `ok` false: a component is outside the range where the f32 bound holds
+// (the ray takes the plain walk).
+__device__ __forceinline__ CandRay cand_ray(const RayD& ray, D3 inv_d, bool& ok) {
+    const D3 oi{ray.o.x * inv_d.x, ray.o.y * inv_d.y, ray.o.z * inv_d.z};
+    const double imin = fmin(fabs(inv_d.x), fmin(fabs(inv_d.y), fabs(inv_d.z)));
+    const double imax = fmax(fabs(inv_d.x), fmax(fabs(inv_d.y), fabs(inv_d.z)));
+    const double omax = fmax(fabs(oi.x), fmax(fabs(oi.y), fabs(oi.z)));
+    // f32's normal range with room for the products; CAND_MIN_BOUND * CAND_SLACK * 1e-18 is still far above the
+    // smallest f32 step, which bounds what a result in the denormal range loses
+    ok = imin > 1e-18 && imax < 1e18 && omax < 1e18 && fabs(ray.time) < 1e9;
+    return CandRay{{(float)inv_d.x, (float)inv_d.y, (float)inv_d.z}, {(float)oi.x, (float)oi.y, (float)oi.z}, (float)ray.time};
+}
 // LDS state of the candidate search. Per lane (columns of [row][threads per workgroup] arrays): a bit per
 // tree node, all zero between queries, in rows 0 .. CAND_WORDS - 1, and in row CAND_WORDS one bit per row
 // that holds marks. Per wave: the work queue of the spatial search, CAND_QUEUE entries.
@@ -1537,58 +1561,54 @@ __device__ bool wave_candidate_search(SceneRef sv, const CandRay& cr, bool askin
         // per-child branch would add its own round trip to the chain of node fetches.
         const DCand4* nd = sv.cand_nodes + node;
         const int4 ch4 = *reinterpret_cast<const int4*>(nd->child);
-        float4 lo4[3], hi4[3];
+        v4f lo4[3], hi4[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            lo4[a] = *reinterpret_cast<const float4*>(nd->lo[a]);
-            hi4[a] = *reinterpret_cast<const float4*>(nd->hi[a]);
+            lo4[a] = *reinterpret_cast<const v4f*>(nd->lo[a]);
+            hi4[a] = *reinterpret_cast<const v4f*>(nd->hi[a]);
         }
-        const bool moving = nd->moving != 0;
+        // (the velocity line too, whether or not the node has a moving child: asked for only after the flag had
+        // arrived, it was a second round trip in a loop that is bound by the chain of its waits)
+        v4f vlo4[3], vhi4[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            vlo4[a] = *reinterpret_cast<const v4f*>(nd->vlo[a]);
+            vhi4[a] = *reinterpret_cast<const v4f*>(nd->vhi[a]);
+        }
         // the constants of the ray this lane works for
         const int from = (int)owner;
-        const double inv[3] = {__shfl(cr.inv[0], from, 64), __shfl(cr.inv[1], from, 64), __shfl(cr.inv[2], from, 64)};
-        const double oi[3] = {__shfl(cr.oi[0], from, 64), __shfl(cr.oi[1], from, 64), __shfl(cr.oi[2], from, 64)};
-        const double tau = __shfl(cr.tau, from, 64);
+        const float inv[3] = {__shfl(cr.inv[0], from, 64), __shfl(cr.inv[1], from, 64), __shfl(cr.inv[2], from, 64)};
+        const float oi[3] = {__shfl(cr.oi[0], from, 64), __shfl(cr.oi[1], from, 64), __shfl(cr.oi[2], from, 64)};
+        const float tau = __shfl(cr.tau, from, 64);
         if (work) STAMP_COUNT(st, 0);
         STAMP_COUNT_WAVE(st, 4);
-        double bl[3][4], bh[3][4];
+        // a child's box at the ray's time: lo + min(tau * vlo, tau * vhi) .. hi + max(tau * vlo, tau * vhi) (a static
+        // child has zero velocities and keeps its box exactly)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            bl[a][0] = (double)lo4[a].x, bl[a][1] = (double)lo4[a].y, bl[a][2] = (double)lo4[a].z, bl[a][3] = (double)lo4[a].w;
-            bh[a][0] = (double)hi4[a].x, bh[a][1] = (double)hi4[a].y, bh[a][2] = (double)hi4[a].z, bh[a][3] = (double)hi4[a].w;
+            const v4f pl = (v4f)(tau) * vlo4[a], ph = (v4f)(tau) * vhi4[a];
+            lo4[a] += __builtin_elementwise_min(pl, ph);
+            hi4[a] += __builtin_elementwise_max(pl, ph);
         }
-        if (moving) {
-            // tau >= 0: the lower corner moves with the smallest velocity, the upper with the largest; tau < 0: swapped
-            const bool neg = tau < 0.0;
-            const float(*v_for_lo)[4] = neg ? nd->vhi : nd->vlo;
-            const float(*v_for_hi)[4] = neg ? nd->vlo : nd->vhi;
-            float4 vl4[3], vh4[3];
+        // whether the ray's line over [0.001, FLT_MAX] can meet the boxes of the four children at the ray's time (all
+        // three slabs jointly); an absent child has an inside-out box (lo = inf, hi = -inf) and never passes
+        v4f lo = (v4f)(0.001f), hi = (v4f)(FLT_MAX);
+        const float4 scale = *reinterpret_cast<const float4*>(nd->bound);  // bound[3], vel
+        const float tv = 3.f * __builtin_fabsf(tau) * scale.w;
+        const float bnd[3] = {scale.x + tv, scale.y + tv, scale.z + tv};
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                vl4[a] = *reinterpret_cast<const float4*>(v_for_lo[a]);
-                vh4[a] = *reinterpret_cast<const float4*>(v_for_hi[a]);
-            }
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                bl[a][0] = fma(tau, (double)vl4[a].x, bl[a][0]), bl[a][1] = fma(tau, (double)vl4[a].y, bl[a][1]);
-                bl[a][2] = fma(tau, (double)vl4[a].z, bl[a][2]), bl[a][3] = fma(tau, (double)vl4[a].w, bl[a][3]);
-                bh[a][0] = fma(tau, (double)vh4[a].x, bh[a][0]), bh[a][1] = fma(tau, (double)vh4[a].y, bh[a][1]);
-                bh[a][2] = fma(tau, (double)vh4[a].z, bh[a][2]), bh[a][3] = fma(tau, (double)vh4[a].w, bh[a][3]);
-            }
+        for (int a = 0; a < 3; ++a) {
+            const v4f t0 = __builtin_elementwise_fma(lo4[a], (v4f)(inv[a]), (v4f)(-oi[a]));
+            const v4f t1 = __builtin_elementwise_fma(hi4[a], (v4f)(inv[a]), (v4f)(-oi[a]));
+            const float slack = CAND_SLACK * __builtin_fmaf(bnd[a], __builtin_fabsf(inv[a]), __builtin_fabsf(oi[a]));
+            lo = __builtin_elementwise_max(lo, __builtin_elementwise_min(t0, t1) - (v4f)(slack));
+            hi = __builtin_elementwise_min(hi, __builtin_elementwise_max(t0, t1) + (v4f)(slack));
         }
         const int child[4] = {ch4.x, ch4.y, ch4.z, ch4.w};
         LDS_AS uint32_t* column = column0 + owner;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            // whether the ray's line over [0.001, FLT_MAX] can meet the box of child k at the ray's time (all
-            // three slabs jointly); an absent child has an inside-out box (lo = inf, hi = -inf) and never passes
-            double lo = (double)0.001f, hi = (double)FLT_MAX;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double t0 = fma(bl[a][k], inv[a], -oi[a]), t1 = fma(bh[a][k], inv[a], -oi[a]);
-                lo = vmax_f64(lo, vmin_f64(t0, t1)), hi = vmin_f64(hi, vmax_f64(t0, t1));
-            }
-            const bool meets = work && lo <= hi && child[k] != -1;
+            const bool meets = work && lo[k] <= hi[k] && child[k] != -1;
             if (meets && child[k] < 0) {
                 // a leaf: mark it in the bit column of the ray's lane (LDS ORs that return nothing)
                 const int leaf = -2 - child[k];
@@ -1709,9 +1729,10 @@ __device__ bool nearest_hit_lane(SceneRef sv, const RayD& ray, const Rng& g, boo
         const double dmax = fmax(fabs(ray.d.x), fmax(fabs(ray.d.y), fabs(ray.d.z)));
         // (so do origins so far out that origin * inv loses the digits the boxes' safety margin covers)
         const double omax = fmax(fabs(ray.o.x), fmax(fabs(ray.o.y), fabs(ray.o.z)));
-        const bool search = live && dmin > 0.0 && dmax < INFINITY && omax < 1e6;
         D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
-        const CandRay cr{{inv_d.x, inv_d.y, inv_d.z}, {ray.o.x * inv_d.x, ray.o.y * inv_d.y, ray.o.z * inv_d.z}, ray.time};
+        bool in_range;
+        const CandRay cr = cand_ray(ray, inv_d, in_range);
+        const bool search = live && dmin > 0.0 && dmax < INFINITY && omax < 1e6 && in_range;
         REGION_BEGIN(search_t);
         const bool complete = wave_candidate_search(sv, cr, search, lds, st);
         REGION_END(st, ST_CAND_SEARCH, search_t);

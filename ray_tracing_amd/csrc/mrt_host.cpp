@@ -452,7 +452,6 @@ int collapse(const std::vector<Cand2>& b2, int i, std::vector<DCand4>* out, int*
         for (int a = 0; a < 3; ++a) {
             nd.lo[a][k] = down(c.lo[a]), nd.hi[a][k] = up(c.hi[a]);
             nd.vlo[a][k] = down(c.vlo[a]), nd.vhi[a][k] = up(c.vhi[a]);
-            if (c.vlo[a] != 0.0 || c.vhi[a] != 0.0) nd.moving = 1;
         }
     }
     (*out)[(size_t)me] = nd;
@@ -489,6 +488,22 @@ void build_candidate_tree(FlatScene* s) {
         s->cand_nodes.clear();
         return;
     }
+    bool finite = true;
+    for (DCand4& nd : s->cand_nodes) {
+        for (int a = 0; a < 3; ++a) nd.bound[a] = CAND_MIN_BOUND;
+        nd.vel = 0.f;
+        for (int k = 0; k < 4; ++k) {
+            if (nd.child[k] == -1) continue;
+            for (int a = 0; a < 3; ++a) {
+                nd.bound[a] = std::max(nd.bound[a], std::max(std::fabs(nd.lo[a][k]), std::fabs(nd.hi[a][k])));
+                nd.vel = std::max(nd.vel, std::max(std::fabs(nd.vlo[a][k]), std::fabs(nd.vhi[a][k])));
+                finite = finite && std::isfinite(nd.bound[a]);
+            }
+        }
+        finite = finite && std::isfinite(nd.vel);
+    }
+    // (bounds too large for the f32 node format end up infinite: no search then)
+    if (!finite) s->cand_nodes.clear();
 }
 
 int fail(std::string* err, int code, const std::string& msg) {

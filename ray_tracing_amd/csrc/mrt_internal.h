@@ -103,6 +103,7 @@ enum : int32_t {
 constexpr int CAND_WORDS = 32;
 constexpr int CAND_MAX_NODES = CAND_WORDS * 32;
 constexpr int CAND_STACK = 32;
+constexpr float CAND_MIN_BOUND = 1e-6f;
 
 // Device BVH node of the per-lane walk: one 64-byte line per node.
 struct DNode {
@@ -125,17 +126,17 @@ static_assert(sizeof(DLeafRec) == 96, "DLeafRec layout");
 // Node of the spatial tree of the candidate search: four children with their boxes. The search is
 // bound by the cache lines its per-lane (divergent) node loads touch, so a node is two 128-byte lines:
 // the first holds the child links and the boxes at ray time 0, the second the velocity bounds, which only
-// nodes with a moving child read. Bounds are f32, rounded OUTWARD from the f64 boxes on the host (lower
+// nodes with a moving child need. Bounds are f32, rounded OUTWARD from the f64 boxes on the host (lower
 // bounds down, upper bounds up), so the stored boxes contain the exact ones and the search stays a
-// superset filter; the device converts them back to f64 and tests in f64.
+// superset filter; the device tests them in f32 with the rounding error added to the comparison.
 // A child's box at ray time tau is [lo + min(tau * vlo, tau * vhi), hi + max(tau * vlo, tau * vhi)]: a
 // MovingSphere's centre is linear in the ray's time (sphere.rs:139-142), and scattered rays carry arbitrary
 // times (ray_tracer.rs:242,261 set time = hit t), so the bound has to hold for every tau.
 struct alignas(128) DCand4 {
     int32_t child[4];  // >= 0: node index; -1: none; <= -2: leaf, index (-2 - child) in FlatScene::nodes
     float lo[3][4], hi[3][4];
-    int32_t moving;    // 0: every velocity bound is 0 (the second line is not read)
-    int32_t pad[3];
+    float bound[3];    // per axis: the largest |lo|, |hi| of the children (at least CAND_MIN_BOUND): scale of the device's f32 rounding bound
+    float vel;         // the largest |velocity bound| of the children, any axis
     float vlo[3][4], vhi[3][4];  // velocity bounds per unit of ray time
     int32_t pad2[8];
 };
