@@ -1499,7 +1499,10 @@ __device__ __forceinline__ bool lane_visit(SceneRef sv, const DNode& nd, const D
 // 1.5 u S for the rounding of S itself and of the widened ends. (The slack matters: a bounced ray starts ON a
 // sphere, whose slab interval ends at t = 0 just below the query's 0.001; one slack for the whole tree -- its
 // largest bound is the ground sphere's 2000 -- marked that sphere for most rays, 12 % of the kernel.)
-constexpr float CAND_SLACK = 4.5f * 0x1p-24f;
+#ifndef MRT_CAND_SLACK_U
+#define MRT_CAND_SLACK_U 4.5f  // (a build with 0 must fail tests/test_candidate_search.py)
+#endif
+constexpr float CAND_SLACK = MRT_CAND_SLACK_U * 0x1p-24f;
 struct CandRay {
     float inv[3], oi[3];
     float tau;  // the ray's time

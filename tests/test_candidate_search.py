@@ -87,6 +87,66 @@ def test_candidate_search_equals_tree_walk(seed, n):
     np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)   # f32 atomic adds: order-dependent last bits
 
 
+def hard_rays(world, n, seed):
+    """Rays that stress the search's single-precision slab tests, with small, large and negative ray times.
+    Half of them graze a sphere where it touches its box: they run almost inside the tangent plane at one of the six
+    poles, a few parts in 1e8 .. 1e6 of the coordinate below it -- inside the sphere by less than f32 resolves at
+    that coordinate, so an f32 slab test without its rounding bound puts many of them outside the box (a build with
+    MRT_CAND_SLACK_U=0 fails this test on dozens of rays). The others aim at corners, edges and face centres of
+    the boxes from near and far, some almost parallel to an axis."""
+    rng = np.random.default_rng(seed)
+    spheres = [(np.array(o.shape.origin), abs(o.shape.radius), None) for o in world.objects[1:]
+               if isinstance(o.shape, S.Sphere)]
+    movers = [(np.array(o.shape.center_0), abs(o.shape.radius), o.shape) for o in world.objects[1:]
+              if isinstance(o.shape, S.MovingSphere) and np.array_equal(o.transform.world_transform, np.eye(4))]
+    rays = np.zeros((n, 7))
+    for i in range(n):
+        time = float(rng.choice([0.0, 0.3, 1.0, 7.5, 40.0, -2.5, 900.0]))
+        if movers and rng.random() < 0.5:
+            c0, r, sh = movers[rng.integers(len(movers))]
+            c = c0 + (time - sh.time_0) / (sh.time_1 - sh.time_0) * (np.array(sh.center_1) - c0)   # sphere.rs:139-142
+        else:
+            c, r, _ = spheres[rng.integers(len(spheres))]
+        if i % 2 == 0:
+            a, sgn = int(rng.integers(0, 3)), float(rng.choice([-1.0, 1.0]))
+            pole = c.copy()
+            pole[a] += sgn * r
+            below = (abs(pole[a]) + 1.0) * float(rng.choice([1e-8, 1e-7, 3e-7, 1e-6]))
+            q = pole.copy()
+            q[a] -= sgn * below
+            d = rng.normal(size=3)
+            d[a] = 0.0
+            d /= np.linalg.norm(d)
+            d[a] = float(rng.choice([1e-9, -1e-9, 1e-6, -1e-6, 1e-4]))       # (exactly 0 would take the walk)
+            o = q - float(rng.choice([0.5, 5.0, 50.0])) * d
+            d = d * float(rng.choice([1.0, 1e-3, 250.0]))
+        else:
+            corner = rng.integers(-1, 2, 3).astype(float)           # a corner, an edge or face centre, or the centre
+            target = c + r * corner * (1.0 + float(rng.choice([0.0, 1e-7, -1e-7, 1e-9, -1e-9, 1e-12])))
+            far = float(rng.choice([0.5, 3.0, 30.0, 3000.0, 4e5]))
+            o = target + far * rng.normal(size=3)
+            d = (target - o) * float(rng.choice([1.0, 1e-3, 250.0]))
+            k = rng.integers(0, 4)
+            if k < 3 and rng.random() < 0.3:
+                d[k] = float(rng.choice([1e-12, -1e-12, 1e-7])) * np.abs(d).max()     # almost parallel to an axis
+        rays[i, 0:3], rays[i, 3:6], rays[i, 6] = o, d, time
+    return rays
+
+
+def test_candidate_search_on_grazing_and_extreme_rays():
+    info = crowded_scene(6, 500)
+    rt = RayTracer(info, device=0, seed=6)
+    rays = hard_rays(info, 60000, 6)
+    rt.world.set_option("traversal", 1)
+    o1, t1, n1, p1, f1 = rt.world.trace_rays(rays, seed=6)
+    rt.world.set_option("traversal", 4)
+    o4, t4, n4, p4, f4 = rt.world.trace_rays(rays, seed=6)
+    assert (o1 > 0).sum() > len(rays) // 10       # (object 0 is the ground)
+    bad = np.flatnonzero((o1 != o4) | (t1 != t4))
+    assert len(bad) == 0, f"{len(bad)} rays differ, first {bad[:5]}: {rays[bad[:2]]}"
+    assert (n1 == n4).all() and (f1 == f4).all()
+
+
 def test_random_scene_image_is_the_walks_image():
     """The reference's random_scene: 369 MovingSpheres whose leaf boxes depend on the running bound."""
     rt = RayTracer(scene_by_name("Random Scene"), device=0, seed=4)
