@@ -1680,6 +1680,9 @@ __device__ bool visit_candidates(SceneRef sv, const RayD& ray, D3 inv_d, const R
     // pre-order.
     int last_parent = -1;
     bool last_parent_pass = true;
+#ifdef MRT_STAMPS
+    int diag_full = 0;
+#endif
     int idx = next_marked();
     DNode nd{};
     DLeafRec lr{};
@@ -1691,6 +1694,9 @@ __device__ bool visit_candidates(SceneRef sv, const RayD& ray, D3 inv_d, const R
         if (idx_next >= 0) nd_next = sv.nodes[idx_next], lr_next = sv.lane_leaf[idx_next];
         STAMP_COUNT(st, 2);
         STAMP_COUNT_WAVE(st, 5);
+#ifdef MRT_STAMPS
+        if (lr.kind == MRT_SHAPE_SPHERE && lr.identity == 1) STAMP_COUNT(st, 11); else diag_full++;
+#endif
         bool reach = true;
         if constexpr ((FEAT & FEAT_MOVING) != 0) {
             if (nd.flags & NODE_DYNAMIC_BOX) {
@@ -1712,6 +1718,12 @@ __device__ bool visit_candidates(SceneRef sv, const RayD& ray, D3 inv_d, const R
         nd = nd_next;
         lr = lr_next;
     }
+#ifdef MRT_STAMPS
+    for (int k = 1; k < 64; ++k) {  // rounds the wave would need if visits of untransformed static spheres cost nothing
+        if (__ballot(diag_full >= k) == 0) break;
+        STAMP_COUNT_WAVE(st, 10);
+    }
+#endif
     out.t = w.closest;
     out.obj = w.best_obj;
     out.sub = w.best_sub;
@@ -3690,6 +3702,9 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
                      (double)host.stamp_counts[4] / (double)std::max(1ull, host.stamp_counts[6]),
                      (double)host.stamp_counts[5] / (double)std::max(1ull, host.stamp_counts[6]),
                      (double)host.stamp_counts[3] / (double)std::max(1ull, host.stamp_counts[6]));
+        std::fprintf(stderr, "[stamps] leaf visits of untransformed static spheres: %.2f per query; rounds of leaf visits without them: %.1f per wave and query\n",
+                     (double)host.stamp_counts[11] / (double)std::max(1ull, host.stamp_counts[3]),
+                     (double)host.stamp_counts[10] / (double)std::max(1ull, host.stamp_counts[6]));
         {
             unsigned long long od[6] = {0, 0, 0, 0, 0, 0};
             (void)hipMemcpyFromSymbol(od, HIP_SYMBOL(g_oct_diag), sizeof(od));
