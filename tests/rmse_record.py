@@ -15,6 +15,8 @@ that does, and says so in the row (`spp`, `spp_wanted`).
 
   python tests/rmse_record.py --rows small --out profiles/r03_rmse.json
   python tests/rmse_record.py --rows full  --out profiles/r03_rmse.json      (merges into the same file)
+  python tests/rmse_record.py --rows random --checker-only --cache tests/_rmse_cache --cpu-seconds 5000   (no GPU needed)
+  python tests/rmse_record.py --rows random --cache tests/_rmse_cache --cpu-seconds 5000 --out profiles/r03_rmse.json
 """
 from __future__ import annotations
 
@@ -33,6 +35,9 @@ if ROOT not in sys.path:
 SMALL = [("Cornell Smoke", 480, 270, 1024), ("Light Demonstration", 480, 270, 1024), ("Voxel City", 480, 270, 1024),
          ("Random Scene", 240, 135, 1024)]
 FULL = [("Cornell Smoke", 1920, 1080, 1024)]
+# Random Scene at the protocol's size: an hour per checker image, so its two images are rendered beforehand
+# (`--checker-only --cache DIR`, any host) and the GPU box only compares (`--cache DIR`).
+RANDOM = [("Random Scene", 480, 270, 1024)]
 
 
 def display(x):
@@ -74,8 +79,25 @@ def compare(g, a, b, f):
             "channel_mean_ratio": ratio.tolist(), "checker_mean_noise": noise.tolist(), "pass_means": ok_means}
 
 
-def run_row(name, W, H, spp_wanted, cpu_seconds, threads):
-    from ray_tracing_amd import ParallelImage, RayTracer, scenarios
+def cached_checker(cache, ow, name, W, H, spp, seed, threads, label):
+    """checker_render through a directory of finished images (`<scene>_<W>x<H>_<spp>spp_seed<seed>.npy` + `.json`)."""
+    if not cache:
+        a, s = checker_render(ow, W, H, spp, seed, threads, label)
+        return a, s, threads
+    stem = os.path.join(cache, f"{name.lower().replace(' ', '_')}_{W}x{H}_{spp}spp_seed{seed}")
+    if os.path.exists(stem + ".npy"):
+        meta = json.load(open(stem + ".json"))
+        print(f"  {label}: from {stem}.npy ({meta['seconds']:.0f} s on {meta['threads']} threads when it was rendered)", flush=True)
+        return np.load(stem + ".npy"), meta["seconds"], meta["threads"]
+    a, s = checker_render(ow, W, H, spp, seed, threads, label)
+    os.makedirs(cache, exist_ok=True)
+    np.save(stem + ".npy", a)
+    json.dump({"seconds": s, "threads": threads}, open(stem + ".json", "w"))
+    return a, s, threads
+
+
+def run_row(name, W, H, spp_wanted, cpu_seconds, threads, cache=None, checker_only=False):
+    from ray_tracing_amd import scenarios
     from tests.oracle_ffi import OracleWorld
 
     info = scenarios.build_with_assets(name, os.path.join(ROOT, "tests", "golden"))
@@ -90,14 +112,20 @@ def run_row(name, W, H, spp_wanted, cpu_seconds, threads):
     while spp > 8 and W * H * spp / rate > cpu_seconds:
         spp //= 2
     print(f"{name} {W}x{H}: checker {rate / 1e6:.3f} Mpaths/s on {threads} threads -> {spp} spp (wanted {spp_wanted})", flush=True)
+    if checker_only:
+        cached_checker(cache, ow, name, W, H, spp, 100, threads, "checker a")
+        cached_checker(cache, ow, name, W, H, spp, 200, threads, "checker b")
+        return None
+    from ray_tracing_amd import ParallelImage, RayTracer
     rt = RayTracer(info, device=0, seed=3)
     img = ParallelImage.new_black(W, H)
     t0 = time.perf_counter()
     st = rt.trace_part(img.split(1)[0], spp, first_sample=0)
     gpu_s = time.perf_counter() - t0
     g = img.buffer / np.float32(spp)
-    a, sa = checker_render(ow, W, H, spp, 100, threads, "checker a")
-    b, sb = checker_render(ow, W, H, spp, 200, threads, "checker b")
+    a, sa, threads_a = cached_checker(cache, ow, name, W, H, spp, 100, threads, "checker a")
+    b, sb, threads_b = cached_checker(cache, ow, name, W, H, spp, 200, threads, "checker b")
+    threads = threads_a if threads_a == threads_b else [threads_a, threads_b]
     row = {"scene": name, "width": W, "height": H, "spp": spp, "spp_wanted": spp_wanted,
            "gpu": {"seed": 3, "generator": "addressed (include/mrt.h)", "seconds": gpu_s, "rays": int(st.rays)},
            "checker": {"seeds": [100, 200], "generator": "sequential mt19937_64", "threads": threads,
@@ -112,7 +140,9 @@ def run_row(name, W, H, spp_wanted, cpu_seconds, threads):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--rows", default="small", choices=["small", "full", "all"])
+    ap.add_argument("--rows", default="small", choices=["small", "full", "all", "random"])
+    ap.add_argument("--cache", default=None, help="directory of finished checker images (read, and written when missing)")
+    ap.add_argument("--checker-only", action="store_true", help="render the checker images into --cache and stop (no GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=150.0, help="bound of one checker image")
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "rmse.json"))
@@ -122,7 +152,7 @@ def main():
     except AttributeError:
         usable = os.cpu_count() or 1
     threads = args.threads or min(16, usable)
-    rows = {"small": SMALL, "full": FULL, "all": SMALL + FULL}[args.rows]
+    rows = {"small": SMALL, "full": FULL, "all": SMALL + FULL, "random": RANDOM}[args.rows]
     doc = {"protocol": "R_cc = RMSE(checker a, checker b), R_gc = mean RMSE(GPU, checker a|b) at equal spp on accum / spp; "
                        "pass iff R_gc <= 1.15 R_cc and channel means within 0.5 % + 2 x |mean a - mean b|, on linear and on "
                        "clamp(sqrt(x)) values", "rows": []}
@@ -132,7 +162,9 @@ def main():
         except ValueError:
             pass
     for name, W, H, spp in rows:
-        row = run_row(name, W, H, spp, args.cpu_seconds, threads)
+        row = run_row(name, W, H, spp, args.cpu_seconds, threads, args.cache, args.checker_only)
+        if row is None:
+            continue
         doc["rows"] = [r for r in doc["rows"] if (r["scene"], r["width"], r["height"]) != (name, W, H)] + [row]
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         with open(args.out, "w") as f:
