@@ -524,6 +524,25 @@ __device__ __forceinline__ bool sphere_hit(D3 c, double radius, const RayD& r, d
     t_out = root;
     return true;
 }
+// An upper bound (f32, rounded up) on the nearest hit of a ray, from one sphere the ray is known to meet: the far root of
+// sphere_hit's own quadratic, evaluated with sphere_hit's expressions. If that root is a valid answer (>= t_min with
+// room to spare), sphere_hit on this sphere returns it or the near root, whichever it accepts first, unless the running
+// bound is below them already: either way the query ends at or below the far root. INFINITY when there is no such root.
+// (Where it pays: the reference's Dielectric does not flip the normal for a ray that leaves the glass, its Schlick term
+// exceeds 1 there and the ray always reflects -- material.rs:141-196 -- so a path that enters a glass sphere bounces
+// inside it until the depth limit, and 71 % of the random-spheres scene's rays start on a sphere pointing into it.)
+__device__ __forceinline__ float sphere_far_root_cap(D3 c, double radius, const RayD& r) {
+#pragma clang fp contract(off)
+    const double rx = r.o.x - c.x, ry = r.o.y - c.y, rz = r.o.z - c.z;
+    double a = fma(r.d.z, r.d.z, fma(r.d.y, r.d.y, r.d.x * r.d.x));
+    double half_b = fma(rz, r.d.z, fma(ry, r.d.y, rx * r.d.x));
+    double cc = fma(-radius, radius, fma(rz, rz, fma(ry, ry, rx * rx)));
+    double disc = fma(-a, cc, half_b * half_b);
+    if (!(disc >= 0.0)) return INFINITY;
+    const double far_root = (-half_b + sqrt(disc)) * rcp_fast(a);
+    if (!(far_root >= 0.002 && far_root < 1e30)) return INFINITY;
+    return (float)(far_root * 1.0000002);  // (more than half an f32 step: rounded up whatever the conversion does)
+}
 // The two boundary queries of a medium around a Sphere (constant_medium.rs:36-44): sphere_hit over
 // [-1e10, 1e10], then over [t1 + 1e-4, 1e10]. Both answers are roots of the same quadratic, so the discriminant,
 // its square root and the reciprocal are worked out once; the choice of the root is sphere_hit's, per query.
@@ -1506,11 +1525,12 @@ constexpr float CAND_SLACK = MRT_CAND_SLACK_U * 0x1p-24f;
 struct CandRay {
     float inv[3], oi[3];
     float tau;  // the ray's time
+    float cap;  // leaves whose boxes the line enters beyond this t are not wanted (FLT_MAX: all of them)
 };
 typedef float v4f __attribute__((ext_vector_type(4)));
 // The constants of a ray for the search; `ok` false: a component is outside the range where the f32 bound holds
 // (the ray takes the plain walk).
-__device__ __forceinline__ CandRay cand_ray(const RayD& ray, D3 inv_d, bool& ok) {
+__device__ __forceinline__ CandRay cand_ray(const RayD& ray, D3 inv_d, float cap, bool& ok) {
     const D3 oi{ray.o.x * inv_d.x, ray.o.y * inv_d.y, ray.o.z * inv_d.z};
     const double imin = fmin(fabs(inv_d.x), fmin(fabs(inv_d.y), fabs(inv_d.z)));
     const double imax = fmax(fabs(inv_d.x), fmax(fabs(inv_d.y), fabs(inv_d.z)));
@@ -1518,7 +1538,8 @@ __device__ __forceinline__ CandRay cand_ray(const RayD& ray, D3 inv_d, bool& ok)
     // f32's normal range with room for the products; CAND_MIN_BOUND * CAND_SLACK * 1e-18 is still far above the
     // smallest f32 step, which bounds what a result in the denormal range loses
     ok = imin > 1e-18 && imax < 1e18 && omax < 1e18 && fabs(ray.time) < 1e9;
-    return CandRay{{(float)inv_d.x, (float)inv_d.y, (float)inv_d.z}, {(float)oi.x, (float)oi.y, (float)oi.z}, (float)ray.time};
+    return CandRay{{(float)inv_d.x, (float)inv_d.y, (float)inv_d.z}, {(float)oi.x, (float)oi.y, (float)oi.z}, (float)ray.time,
+                   cap < FLT_MAX ? cap : FLT_MAX};
 }
 // LDS state of the candidate search. Per lane (columns of [row][threads per workgroup] arrays): a bit per
 // tree node, all zero between queries, in rows 0 .. CAND_WORDS - 1, and in row CAND_WORDS one bit per row
@@ -1583,6 +1604,7 @@ __device__ bool wave_candidate_search(SceneRef sv, const CandRay& cr, bool askin
         const float inv[3] = {__shfl(cr.inv[0], from, 64), __shfl(cr.inv[1], from, 64), __shfl(cr.inv[2], from, 64)};
         const float oi[3] = {__shfl(cr.oi[0], from, 64), __shfl(cr.oi[1], from, 64), __shfl(cr.oi[2], from, 64)};
         const float tau = __shfl(cr.tau, from, 64);
+        const float cap = __shfl(cr.cap, from, 64);
         if (work) STAMP_COUNT(st, 0);
         STAMP_COUNT_WAVE(st, 4);
         // a child's box at the ray's time: lo + min(tau * vlo, tau * vhi) .. hi + max(tau * vlo, tau * vhi) (a static
@@ -1595,7 +1617,7 @@ __device__ bool wave_candidate_search(SceneRef sv, const CandRay& cr, bool askin
         }
         // whether the ray's line over [0.001, FLT_MAX] can meet the boxes of the four children at the ray's time (all
         // three slabs jointly); an absent child has an inside-out box (lo = inf, hi = -inf) and never passes
-        v4f lo = (v4f)(0.001f), hi = (v4f)(FLT_MAX);
+        v4f lo = (v4f)(0.001f), hi = (v4f)(cap);
         const float4 scale = *reinterpret_cast<const float4*>(nd->bound);  // bound[3], vel
         const float tv = 3.f * __builtin_fabsf(tau) * scale.w;
         const float bnd[3] = {scale.x + tv, scale.y + tv, scale.z + tv};
@@ -1638,7 +1660,7 @@ __device__ bool wave_candidate_search(SceneRef sv, const CandRay& cr, bool askin
 // With `discard` the marks are only cleared.
 template <int FEAT>
 __device__ bool visit_candidates(SceneRef sv, const RayD& ray, D3 inv_d, const Rng& g, HitD& out, CandLds lds, bool discard,
-                                 Stamps& st) {
+                                 Stamps& st, float cap = FLT_MAX, bool* retry = nullptr) {
     LDS_AS uint32_t* bits = lds.bits;
     static_assert(CAND_WORDS <= 32, "one summary bit per word");
     uint32_t touched = bits[CAND_WORDS * lds.stride];  // which words of the bit array hold marks
@@ -1700,6 +1722,16 @@ __device__ bool visit_candidates(SceneRef sv, const RayD& ray, D3 inv_d, const R
         bool reach = true;
         if constexpr ((FEAT & FEAT_MOVING) != 0) {
             if (nd.flags & NODE_DYNAMIC_BOX) {
+                // The search ran under `cap`, an upper bound on this query's answer, and left out the leaves whose
+                // boxes the line enters beyond it. Their hits, all beyond the cap, cannot be the answer, but the walk
+                // would have visited them and they would have moved its running bound, on which the box of THIS
+                // leaf (and the parent test in front of it) depends. Once the bound is at or below the cap they are
+                // out of the picture -- a hit beyond the bound is never accepted -- and the bound here is the walk's;
+                // above the cap it may not be, and the query is put to the uncapped search (see nearest_hit_lane).
+                if (w.closest > (double)cap) {
+                    *retry = true;
+                    reach = false;
+                } else
                 if (nd.parent != last_parent) {
                     last_parent = nd.parent;
                     last_parent_pass = true;
@@ -1714,6 +1746,12 @@ __device__ bool visit_candidates(SceneRef sv, const RayD& ray, D3 inv_d, const R
             }
         }
         if (reach) (void)lane_visit<FEAT>(sv, nd, lr, ray, inv_d, g, w);
+        if constexpr ((FEAT & FEAT_MOVING) != 0) {
+            if (cap < FLT_MAX && *retry) {  // nothing of this pass is kept: clear the marks that are left
+                if (idx_next >= 0) while (next_marked() >= 0) {}
+                return false;
+            }
+        }
         idx = idx_next;
         nd = nd_next;
         lr = lr_next;
@@ -1735,7 +1773,7 @@ __device__ bool visit_candidates(SceneRef sv, const RayD& ray, D3 inv_d, const R
 // the lanes with a ray.
 template <int FEAT>
 __device__ bool nearest_hit_lane(SceneRef sv, const RayD& ray, const Rng& g, bool live, HitD& out, Stamps& st,
-                                 CandLds lds = CandLds{nullptr, nullptr, 0}) {
+                                 CandLds lds = CandLds{nullptr, nullptr, 0}, float cap = INFINITY, bool* retry = nullptr) {
     // (`stride`, not a pointer, says whether the kernel has the search's LDS arrays: LDS address 0 is thread 0's
     // column, and the test must come out the same for the whole wave)
     if (sv.n_cand_nodes > 0 && lds.stride != 0) {
@@ -1746,14 +1784,26 @@ __device__ bool nearest_hit_lane(SceneRef sv, const RayD& ray, const Rng& g, boo
         const double omax = fmax(fabs(ray.o.x), fmax(fabs(ray.o.y), fabs(ray.o.z)));
         D3 inv_d{rcp_fast(ray.d.x), rcp_fast(ray.d.y), rcp_fast(ray.d.z)};
         bool in_range;
-        const CandRay cr = cand_ray(ray, inv_d, in_range);
+        // `cap`: an upper bound on this query's answer that the caller knows (INFINITY if none): the search leaves out
+        // what lies beyond it. With leaves whose boxes depend on the running bound that is not always enough to
+        // reproduce the walk (visit_candidates); `*retry` then comes back true, the lane has no answer, and the caller
+        // asks again without a cap -- in the kernel loop's next turn, where the search runs for the whole wave anyway.
+        const CandRay cr = cand_ray(ray, inv_d, retry ? cap : INFINITY, in_range);
         const bool search = live && dmin > 0.0 && dmax < INFINITY && omax < 1e6 && in_range;
         REGION_BEGIN(search_t);
         const bool complete = wave_candidate_search(sv, cr, search, lds, st);
         REGION_END(st, ST_CAND_SEARCH, search_t);
         if (search) {
-            const bool hit = visit_candidates<FEAT>(sv, ray, inv_d, g, out, lds, !complete, st);
-            if (complete) return hit;
+            bool again = false;
+            const bool hit = visit_candidates<FEAT>(sv, ray, inv_d, g, out, lds, !complete, st, cr.cap, &again);
+            if (complete) {
+                if (again) {
+                    *retry = true;
+                    STAMP_COUNT(st, 8);
+                    return false;
+                }
+                return hit;
+            }
         }
     }
     if (!live) return false;
@@ -2623,7 +2673,7 @@ __device__ bool shade_prepare(SceneRef sv, const RayD& ray, const F3& thr, const
 // `unit_vec`: rand_unit_vec at the dimensions shade_prepare asked for. `t` = the hit's t.
 template <int FEAT>
 __device__ bool shade_finish(SceneRef sv, RayD& ray, F3& thr, const Rng& g, double t, const ShadeCtx& c, D3 unit_vec,
-                             uint32_t& light_queries, Stamps& st) {
+                             uint32_t& light_queries, Stamps& st, float* cap_out = nullptr) {
     const DObjRec* ob = c.ob;
     const Surface& s = c.s;
     const F3 att = c.att;
@@ -2692,6 +2742,12 @@ __device__ bool shade_finish(SceneRef sv, RayD& ray, F3& thr, const Rng& g, doub
     }
     // A path whose throughput is exactly zero can only ever add 0 (the reference still walks it).
     if (!sv.trace_zero_throughput && thr.r == 0.f && thr.g == 0.f && thr.b == 0.f) return false;
+    if constexpr ((FEAT & FEAT_SPHERE) != 0) {
+        // (kernels with the candidate search: what the next query can be told about its answer; the new ray of an
+        // untransformed sphere is in world space whatever the material)
+        if (cap_out && ob->kind == MRT_SHAPE_SPHERE && ob->identity == 1)
+            *cap_out = sphere_far_root_cap(D3{ob->p[1], ob->p[2], ob->p[3]}, ob->p[0], ray);
+    }
     return true;
 }
 
@@ -2703,7 +2759,7 @@ __device__ bool shade_finish(SceneRef sv, RayD& ray, F3& thr, const Rng& g, doub
 template <bool WAVE, int FEAT>
 __device__ bool path_segment(SceneRef sv, RayD& ray, F3& thr, const Rng& g, bool live, F3& radiance,
                              uint32_t& rays, uint32_t& light_queries, Stamps& st, CandLds cand_bits, PerlinLds pl, bool& walking,
-                             bool may_suspend) {
+                             bool may_suspend, float& next_cap) {
     radiance = {0.f, 0.f, 0.f};
     HitD h{0.0, -1, 0, {0.0, 0.0, 0.0}};
     bool hit;
@@ -2716,7 +2772,11 @@ __device__ bool path_segment(SceneRef sv, RayD& ray, F3& thr, const Rng& g, bool
             hit = nearest_hit_wave<FEAT>(sv, ray, g, live, h, st);
         }
     } else {
-        hit = nearest_hit_lane<FEAT>(sv, ray, g, live, h, st, cand_bits);
+        bool again = false;
+        hit = nearest_hit_lane<FEAT>(sv, ray, g, live, h, st, cand_bits, next_cap, &again);
+        next_cap = INFINITY;
+        walking = again;  // (no answer in this turn: nothing of the path moves, the next turn asks without a cap)
+        live = live && !again;
     }
     REGION_END(st, ST_TRAVERSE, trav);
     REGION_BEGIN(shade);
@@ -2730,7 +2790,7 @@ __device__ bool path_segment(SceneRef sv, RayD& ray, F3& thr, const Rng& g, bool
     REGION_BEGIN(uvec);
     const D3 unit_vec = wave_rand_unit_vec(want_vec, g.base, vec_dim);
     REGION_END(st, ST_UNIT_VEC, uvec);
-    if (more) cont = shade_finish<FEAT>(sv, ray, thr, g, h.t, c, unit_vec, light_queries, st);
+    if (more) cont = shade_finish<FEAT>(sv, ray, thr, g, h.t, c, unit_vec, light_queries, st, WAVE ? nullptr : &next_cap);
     REGION_END(st, ST_SHADE, shade);
     return cont;
 }
@@ -2839,6 +2899,7 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
     }
     uint32_t rays = 0, light_queries = 0;
     bool walking = false;  // this lane's octree walk was suspended in the previous turn of the loop (nearest_hit_wave)
+    float next_cap = INFINITY;  // per-lane kernels: an upper bound on the answer of the path's next query (not kept across launches)
     uint32_t ended = 0;  // paths of this wave that ended in this launch (wave-uniform: a scalar register)
     // this wave's share of the work range (wave-uniform)
     const uint32_t wave_id = __builtin_amdgcn_readfirstlane(slot >> 6);
@@ -2942,10 +3003,11 @@ __global__ void __launch_bounds__(seg_block(WAVE), seg_waves(WAVE, FEAT)) k_segm
         // a walk still suspended when the launch ends starts again from the ray in the next one)
         const bool may_suspend = step + 1 < steps;
         bool cont = path_segment<WAVE, FEAT>(sv, ray, thr, g, live, radiance, rays, light_queries, st, cand_bits, perlin_lds, walking,
-                                             may_suspend);
+                                             may_suspend, next_cap);
         REGION_BEGIN(acc);
         const bool answered = live && !walking;  // (`walking`: the segment goes on in the next turn, nothing of the path moves)
         if (answered && cont && seg >= 49) cont = false;  // depth 50 -> 0 returns BLACK (ray_tracer.rs:166-172, :451)
+        if (!(answered && cont)) next_cap = INFINITY;
         ended += (uint32_t)__popcll(__ballot(answered && !cont));
         if (answered) {
             seg++;
@@ -3702,6 +3764,7 @@ int render_device(mrt_scene* sc, float* accum_dev, uint32_t width, uint32_t heig
                      (double)host.stamp_counts[4] / (double)std::max(1ull, host.stamp_counts[6]),
                      (double)host.stamp_counts[5] / (double)std::max(1ull, host.stamp_counts[6]),
                      (double)host.stamp_counts[3] / (double)std::max(1ull, host.stamp_counts[6]));
+        std::fprintf(stderr, "[stamps] queries asked again without the caller's cap: %llu\n", host.stamp_counts[8]);
         std::fprintf(stderr, "[stamps] leaf visits of untransformed static spheres: %.2f per query; rounds of leaf visits without them: %.1f per wave and query\n",
                      (double)host.stamp_counts[11] / (double)std::max(1ull, host.stamp_counts[3]),
                      (double)host.stamp_counts[10] / (double)std::max(1ull, host.stamp_counts[6]));

@@ -49,17 +49,29 @@ def rmse(a, b):
     return float(np.sqrt(np.mean(d * d)))
 
 
-def checker_render(ow, W, H, spp, seed, threads, label):
-    """One checker image in sample-range chunks (a progress line per chunk)."""
+def checker_render(ow, W, H, spp, seed, threads, label, partial=None):
+    """One checker image in sample-range chunks (a progress line per chunk). `partial`: file stem that keeps the
+    accumulation after every chunk, so that an interrupted render of an hour goes on where it stopped."""
     acc = np.zeros((H, W, 3), dtype=np.float32)
-    chunk = max(1, spp // 8)
-    t0 = time.perf_counter()
-    done = 0
+    chunk = max(1, spp // 16)
+    done, spent = 0, 0.0
+    if partial and os.path.exists(partial + ".partial.json"):
+        meta = json.load(open(partial + ".partial.json"))
+        acc, done, spent = np.load(partial + ".partial.npy"), meta["done"], meta["seconds"]
+        print(f"  {label}: resuming at {done}/{spp} spp", flush=True)
+    t0 = time.perf_counter() - spent
     while done < spp:
         n = min(chunk, spp - done)
         ow.render(W, H, n, seed=seed, first_sample=done, threads=threads, rng_mode=1, accum=acc)
         done += n
         print(f"  {label}: {done}/{spp} spp, {time.perf_counter() - t0:.1f} s", flush=True)
+        if partial:
+            np.save(partial + ".partial.npy", acc)
+            json.dump({"done": done, "seconds": time.perf_counter() - t0}, open(partial + ".partial.json", "w"))
+    if partial:
+        for ext in (".partial.npy", ".partial.json"):
+            if os.path.exists(partial + ext):
+                os.remove(partial + ext)
     return acc / np.float32(spp), time.perf_counter() - t0
 
 
@@ -89,8 +101,8 @@ def cached_checker(cache, ow, name, W, H, spp, seed, threads, label):
         meta = json.load(open(stem + ".json"))
         print(f"  {label}: from {stem}.npy ({meta['seconds']:.0f} s on {meta['threads']} threads when it was rendered)", flush=True)
         return np.load(stem + ".npy"), meta["seconds"], meta["threads"]
-    a, s = checker_render(ow, W, H, spp, seed, threads, label)
     os.makedirs(cache, exist_ok=True)
+    a, s = checker_render(ow, W, H, spp, seed, threads, label, partial=stem)
     np.save(stem + ".npy", a)
     json.dump({"seconds": s, "threads": threads}, open(stem + ".json", "w"))
     return a, s, threads
