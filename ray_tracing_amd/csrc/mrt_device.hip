@@ -1728,7 +1728,11 @@ __device__ bool visit_candidates(SceneRef sv, const RayD& ray, D3 inv_d, const R
                 // leaf (and the parent test in front of it) depends. Once the bound is at or below the cap they are
                 // out of the picture -- a hit beyond the bound is never accepted -- and the bound here is the walk's;
                 // above the cap it may not be, and the query is put to the uncapped search (see nearest_hit_lane).
+#ifdef MRT_MUTANT_NO_RETRY  // (a build with this must fail tests/test_candidate_search.py::test_capped_queries_reproduce_the_walk)
+                if (false) {
+#else
                 if (w.closest > (double)cap) {
+#endif
                     *retry = true;
                     reach = false;
                 } else

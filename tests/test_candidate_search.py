@@ -147,6 +147,24 @@ def test_candidate_search_on_grazing_and_extreme_rays():
     assert (n1 == n4).all() and (f1 == f4).all()
 
 
+@pytest.mark.parametrize("opts", [dict(segments_per_launch=2), dict(segments_per_launch=5, pool_slots=4096)])
+def test_capped_queries_across_launch_ends(opts):
+    """A query from inside a sphere runs under the sphere's exit distance as a cap (a ray that enters a Dielectric
+    sphere stays inside: the reference always reflects on the way out), and one that meets a MovingSphere leaf before
+    its bound is below the cap is put off to the next turn without it. The cap travels with the path, so only renders
+    exercise it; here with launches so short that the put-off queries meet the end of their launch. (A build with
+    MRT_MUTANT_NO_RETRY fails this test and the two renders above.)"""
+    rt = RayTracer(crowded_scene(2, 300), device=0, seed=2)
+    rt.world.set_option("traversal", 1)
+    a, sa = gpu_render(rt, 160, 90, 4)
+    for k, v in opts.items():
+        rt.world.set_option(k, v)
+    rt.world.set_option("traversal", 4)
+    b, sb = gpu_render(rt, 160, 90, 4)
+    assert sa.rays == sb.rays and sa.paths == sb.paths
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
 def test_random_scene_image_is_the_walks_image():
     """The reference's random_scene: 369 MovingSpheres whose leaf boxes depend on the running bound."""
     rt = RayTracer(scene_by_name("Random Scene"), device=0, seed=4)
