@@ -524,15 +524,30 @@ __device__ __forceinline__ bool sphere_hit(D3 c, double radius, const RayD& r, d
     t_out = root;
     return true;
 }
-// An upper bound (f32, rounded up) on the nearest hit of a ray, from one sphere the ray is known to meet: the far root of
-// sphere_hit's own quadratic, evaluated with sphere_hit's expressions. If that root is a valid answer (>= t_min with
-// room to spare), sphere_hit on this sphere returns it or the near root, whichever it accepts first, unless the running
-// bound is below them already: either way the query ends at or below the far root. INFINITY when there is no such root.
+// An upper bound (f32, rounded up) on the nearest hit of a ray that starts on an untransformed Sphere: the far root of
+// sphere_hit's own quadratic for that sphere, evaluated with sphere_hit's expressions. If the root is a valid answer
+// (>= t_min with room to spare), sphere_hit on this sphere returns it or the near root, whichever it accepts first,
+// unless the running bound is below them already: either way the query ends at or below the far root -- provided the
+// walk gets to test the sphere at all, i.e. the sphere's leaf box (centre -+ radius, the host's expressions) passes
+// Aabb::hit for every running bound >= t_min. That is checked here per axis on the walk's own slab bounds: the
+// entry (box face behind the ray - origin) * (1 / d) has a non-positive numerator, so it is <= 0 whatever the
+// reciprocal's rounding, and the exit's numerator is at least 0.0011 d, so it is >= t_min. A negative radius (inside-out
+// box) gives no bound. INFINITY when there is none.
 // (Where it pays: the reference's Dielectric does not flip the normal for a ray that leaves the glass, its Schlick term
 // exceeds 1 there and the ray always reflects -- material.rs:141-196 -- so a path that enters a glass sphere bounces
 // inside it until the depth limit, and 71 % of the random-spheres scene's rays start on a sphere pointing into it.)
 __device__ __forceinline__ float sphere_far_root_cap(D3 c, double radius, const RayD& r) {
 #pragma clang fp contract(off)
+    if (!(radius > 0.0)) return INFINITY;
+    const double ox[3] = {r.o.x, r.o.y, r.o.z}, dx[3] = {r.d.x, r.d.y, r.d.z}, cx[3] = {c.x, c.y, c.z};
+    bool box_ok = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double lo = (cx[i] - radius) - ox[i], hi = (cx[i] + radius) - ox[i];  // Aabb::hit's numerators
+        const double behind = dx[i] > 0.0 ? lo : -hi, ahead = dx[i] > 0.0 ? hi : -lo;
+        box_ok = box_ok && dx[i] != 0.0 && behind <= 0.0 && ahead >= 0.0011 * fabs(dx[i]);
+    }
+    if (!box_ok) return INFINITY;
     const double rx = r.o.x - c.x, ry = r.o.y - c.y, rz = r.o.z - c.z;
     double a = fma(r.d.z, r.d.z, fma(r.d.y, r.d.y, r.d.x * r.d.x));
     double half_b = fma(rz, r.d.z, fma(ry, r.d.y, rx * r.d.x));
