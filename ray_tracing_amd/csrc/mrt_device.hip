@@ -1489,7 +1489,7 @@ struct LaneWalk {
 // costs one round trip to memory; the object record itself is only touched for objects with a transform.
 template <int FEAT>
 __device__ __forceinline__ bool lane_visit(SceneRef sv, const DNode& nd, const DLeafRec& lr, const RayD& ray, D3 inv_d,
-                                           const Rng& g, LaneWalk& w) {
+                                           const Rng& g, LaneWalk& w, double box_bound) {
     const double t_min = (double)0.001f;
     const int obj = nd.object;
     const int flags = nd.flags;
@@ -1500,9 +1500,10 @@ __device__ __forceinline__ bool lane_visit(SceneRef sv, const DNode& nd, const D
     const double* p = lr.p;
     const bool identity = head.z == 1, translation = head.z == 2;
     if constexpr ((FEAT & FEAT_MOVING) != 0) {
-        if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(ob, p, identity, t_min, w.closest, mn, mx);
+        if (flags & NODE_DYNAMIC_BOX) dynamic_leaf_box(ob, p, identity, t_min, box_bound, mn, mx);
     }
-    if (!aabb_hit(mn, mx, ray, inv_d, t_min, w.closest)) return false;
+    // (`box_bound`: the running bound, except for a leaf visit_candidates tests at its cap)
+    if (!aabb_hit(mn, mx, ray, inv_d, t_min, box_bound)) return false;
     if (obj >= 0) {
         bool is_medium = false;
         if constexpr ((FEAT & FEAT_MEDIUM) != 0) is_medium = head.x == MRT_SHAPE_CONSTANT_MEDIUM;
@@ -1734,23 +1735,28 @@ __device__ bool visit_candidates(SceneRef sv, const RayD& ray, D3 inv_d, const R
 #ifdef MRT_STAMPS
         if (lr.kind == MRT_SHAPE_SPHERE && lr.identity == 1) STAMP_COUNT(st, 11); else diag_full++;
 #endif
-        bool reach = true;
+        bool reach = true, above = false;  // `above`: a query-dependent leaf met with the bound above the search's cap
+        double box_bound = w.closest;
         if constexpr ((FEAT & FEAT_MOVING) != 0) {
             if (nd.flags & NODE_DYNAMIC_BOX) {
                 // The search ran under `cap`, an upper bound on this query's answer, and left out the leaves whose
                 // boxes the line enters beyond it. Their hits, all beyond the cap, cannot be the answer, but the walk
                 // would have visited them and they would have moved its running bound, on which the box of THIS
                 // leaf (and the parent test in front of it) depends. Once the bound is at or below the cap they are
-                // out of the picture -- a hit beyond the bound is never accepted -- and the bound here is the walk's;
-                // above the cap it may not be, and the query is put to the uncapped search (see nearest_hit_lane).
-#ifdef MRT_MUTANT_NO_RETRY  // (a build with this must fail tests/test_candidate_search.py::test_capped_queries_reproduce_the_walk)
-                if (false) {
-#else
-                if (w.closest > (double)cap) {
+                // out of the picture -- a hit beyond the bound is never accepted -- and the bound here is the walk's.
+                // Above the cap the walk's bound is somewhere in [cap, bound here] (it can only be lower: it saw more
+                // leaves). For an untransformed MovingSphere both tests are monotone in the bound -- its box for the
+                // window (t_min, bound) only grows with it, and so does the range of Aabb::hit -- so they are made AT
+                // THE CAP: passing there, they pass for the walk, and the bound kept here stays an upper bound of the
+                // walk's (a hit accepted here beyond the cap is replaced before the query ends). Failing there, or
+                // with a transformed sphere (two mapped corners, hittable.rs:239-282: not monotone), nothing is known
+                // and the query is put to the uncapped search (see nearest_hit_lane).
+                above = w.closest > (double)cap;
+                box_bound = above ? (double)cap : w.closest;
+#ifdef MRT_MUTANT_NO_RETRY  // (a build with this must fail the renders of tests/test_candidate_search.py)
+                above = false, box_bound = w.closest;
 #endif
-                    *retry = true;
-                    reach = false;
-                } else
+                if (above && lr.identity != 1) *retry = true;
                 if (nd.parent != last_parent) {
                     last_parent = nd.parent;
                     last_parent_pass = true;
@@ -1758,13 +1764,19 @@ __device__ bool visit_candidates(SceneRef sv, const RayD& ray, D3 inv_d, const R
                         STAMP_COUNT(st, 1);
                         const DNode pn = sv.nodes[nd.parent];
                         last_parent_pass = aabb_hit(D3{pn.bmin[0], pn.bmin[1], pn.bmin[2]}, D3{pn.bmax[0], pn.bmax[1], pn.bmax[2]}, ray,
-                                                    inv_d, (double)0.001f, w.closest);
+                                                    inv_d, (double)0.001f, box_bound);
+                        if (above && !last_parent_pass) *retry = true;
                     }
                 }
                 reach = last_parent_pass;
             }
         }
-        if (reach) (void)lane_visit<FEAT>(sv, nd, lr, ray, inv_d, g, w);
+        if (reach) {
+            const bool box_passed = lane_visit<FEAT>(sv, nd, lr, ray, inv_d, g, w, box_bound);
+            if constexpr ((FEAT & FEAT_MOVING) != 0) {
+                if (above && !box_passed) *retry = true;
+            }
+        }
         if constexpr ((FEAT & FEAT_MOVING) != 0) {
             if (cap < FLT_MAX && *retry) {  // nothing of this pass is kept: clear the marks that are left
                 if (idx_next >= 0) while (next_marked() >= 0) {}
@@ -1833,7 +1845,7 @@ __device__ bool nearest_hit_lane(SceneRef sv, const RayD& ray, const Rng& g, boo
     while (i < n) {
         const DNode nd = sv.nodes[i];
         const DLeafRec lr = sv.lane_leaf[i];
-        i = lane_visit<FEAT>(sv, nd, lr, ray, inv_d, g, w) ? i + 1 : nd.skip;
+        i = lane_visit<FEAT>(sv, nd, lr, ray, inv_d, g, w, w.closest) ? i + 1 : nd.skip;
     }
     out.t = w.closest;
     out.obj = w.best_obj;
