@@ -154,6 +154,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", default="small", choices=["small", "full", "all", "random"])
     ap.add_argument("--cache", default=None, help="directory of finished checker images (read, and written when missing)")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel instead of the rows' own (e.g. what the cache holds)")
     ap.add_argument("--checker-only", action="store_true", help="render the checker images into --cache and stop (no GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=150.0, help="bound of one checker image")
     ap.add_argument("--threads", type=int, default=0)
@@ -174,6 +175,7 @@ def main():
         except ValueError:
             pass
     for name, W, H, spp in rows:
+        spp = args.spp or spp
         row = run_row(name, W, H, spp, args.cpu_seconds, threads, args.cache, args.checker_only)
         if row is None:
             continue
